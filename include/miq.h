@@ -1,0 +1,145 @@
+/* miq - MI355X (gfx950) int8 quantization hot path, C ABI.
+ *
+ * Drop-in boundary for the quantized hot path of satabios/quantization: the per-channel
+ * int8 weight quantizer, the int8 x int8 -> int32 Linear GEMM with a fused per-channel
+ * dequant epilogue, and the int8 Conv2d as an implicit GEMM.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer on the current HIP device unless it says "host".
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Work is
+ *    enqueued on it; no entry point synchronises or allocates device memory.
+ *  - Return value: 0 on success, a negative MIQ_E* code on failure; miq_last_error() then
+ *    returns a thread-local, human-readable message.  Arguments are validated before
+ *    anything is launched, so a failed call has no effect on device memory.
+ *  - Tensors are dense and contiguous in the stated layout.
+ */
+#ifndef MIQ_H
+#define MIQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIQ_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* error codes */
+#define MIQ_OK 0
+#define MIQ_EINVAL (-1)    /* bad argument: null pointer, negative size, unknown enum     */
+#define MIQ_EALIGN (-2)    /* pointer / leading dimension not aligned as the path needs  */
+#define MIQ_EWORKSPACE (-3) /* workspace missing or too small                             */
+#define MIQ_ELAUNCH (-4)   /* hipGetLastError() != hipSuccess after a launch             */
+#define MIQ_ERANGE (-5)    /* size beyond what the kernels index (2^31 elements / rows)  */
+
+/* element types of floating inputs / outputs */
+#define MIQ_F32 0
+#define MIQ_F16 1
+#define MIQ_BF16 2
+#define MIQ_I32 3 /* outputs only: raw accumulators, no epilogue */
+
+/* layout of the weight operand of miq_gemm_i8 */
+#define MIQ_W_NK 0 /* [N,K], K contiguous: what Quantizer.weight holds (Quantizer.py:33) */
+#define MIQ_W_KN 1 /* [K,N], N contiguous: what linear_w8a8 takes (linear_w8a8_kernel.cu:18) */
+
+int miq_version(void);
+const char* miq_last_error(void);
+
+/* Per-output-channel symmetric int8 weight quantizer.
+ *
+ * Replaces Qop.quantize() with affine='channel', affine_dim=0, symmetric=True, dtype=int8
+ * (quant/Weight_Only/Qop.py:139-162, :74-102, :37-54; identical code in
+ * quant/Weight_Activation/Qop.py:137-160), i.e. for each row n of w[rows, cols]:
+ *     m        = max_k w[n,k]                      (signed maximum, not abs-max)
+ *     scale[n] = max(max(m, 0) / 127.5, 2^-23)     (IEEE division; for f16/bf16 inputs the
+ *                                                   quotient and the floor are rounded to
+ *                                                   that type, returned widened to fp32)
+ *     zp[n]    = 0                                 (int64, as the reference stores it)
+ *     q[n,k]   = int8(clamp(rint(w[n,k] / scale[n]), -128, 127))   (IEEE division,
+ *                                                   round-half-to-even; 16-bit inputs round
+ *                                                   the quotient to their type first)
+ *     row_max[n] = m                               (optional, may be NULL: Qop.max_val)
+ * A 4-D conv weight [Cout,Cin,KH,KW] is passed as rows=Cout, cols=Cin*KH*KW.
+ * w_dtype: MIQ_F32 | MIQ_F16 | MIQ_BF16.  One pass over HBM: 4 B read + 1 B written per
+ * element for fp32.  NaN inputs are outside the contract (the reference's result for
+ * them is a C undefined conversion).
+ */
+int miq_quantize_rows_sym_i8(const void* w, int w_dtype, int64_t rows, int64_t cols, int8_t* q,
+                             float* scale, int64_t* zp, float* row_max, void* stream);
+
+/* The pieces of the quantizer on their own, for callers that use Qop's methods one at a time.
+ *
+ * miq_row_max: row_max[n] = max_k w[n,k], the reduction of Qop.compute_scales_zero_point's
+ * channel branch (quant/Weight_Only/Qop.py:78-92).
+ * miq_quantize_rows_given_i8: Qop.quantize when scales / zero points were computed earlier
+ * (Qop.py:144,154-157): q = int8(clamp(rint(w / scale + zp), -128, 127)); scale (and zp, which
+ * may be NULL for the symmetric form) hold `rows` entries when per_row != 0, else one. */
+int miq_row_max(const void* w, int w_dtype, int64_t rows, int64_t cols, float* row_max, void* stream);
+int miq_quantize_rows_given_i8(const void* w, int w_dtype, int64_t rows, int64_t cols, const float* scale,
+                               const float* zp, int per_row, int8_t* q, void* stream);
+
+/* Weight dequantisation, Qop.dequantize(q) (quant/Weight_Only/Qop.py:179):
+ *     out[n,k] = scale[n] * (float(q[n,k]) - float(zp[n]))        fp32 out
+ * zp may be NULL (treated as zeros). */
+int miq_dequantize_rows_i8(const int8_t* q, const float* scale, const int64_t* zp, int64_t rows,
+                           int64_t cols, float* out, void* stream);
+
+/* Activation-side dequantisation, Qop.dequantize(y, activation=True) (Qop.py:175-179), for a
+ * float tensor y[outer, channels, inner] (inner = 1 for Linear outputs, Ho*Wo for Conv2d):
+ *     out = scale[c] * (y - zp[c])          zp fp32 [channels] or NULL. */
+int miq_dequantize_channels_f32(const float* y, const float* scale, const float* zp, int64_t outer,
+                                int64_t channels, int64_t inner, float* out, void* stream);
+
+/* int8 Linear: out[m,n] = epilogue( sum_k int32(A[m,k]) * int32(W[n,k]) ).
+ *
+ * Replaces linear_w8a8(input, weights) (cuda_kernels/linear_int8/linear_w8a8.cpp:11-20,
+ * linear_w8a8_kernel.cu:5-39) when out_dtype = MIQ_I32 and w_layout = MIQ_W_KN, and the
+ * composition of that product with the dequantisation the Python layers apply after it:
+ *   weight-only   (quant/Weight_Only/Quantizer.py:79-86, Qop.py:179):
+ *       out = scale[n] * ((acc + b[n]) - 0)      -> bias = b, alpha = scale, beta = 0
+ *   weight+activation (quant/Weight_Activation/Quantizer.py:58-60):
+ *       out = (acc + bias'[n]) * scalers[n] + output_zero_point
+ * Epilogue, evaluated in fp32 with one rounding per step (no fused multiply-add):
+ *       out[m,n] = (float(acc[m,n]) + bias[n]) * alpha[n] + beta
+ * A: int8 [M,K] row-major.  W: int8, [N,K] (MIQ_W_NK) or [K,N] (MIQ_W_KN).
+ * bias: fp32 [N] or NULL (no add).  alpha: fp32 [N] (required unless out_dtype = MIQ_I32).
+ * out: [M,N] row-major of out_dtype MIQ_F32 | MIQ_BF16 | MIQ_I32.
+ * workspace: device scratch of at least miq_gemm_i8_workspace(...) bytes, 256-byte
+ * aligned (only MIQ_W_KN needs any: the weight is re-laid [N,K] there first); may be NULL
+ * when that size is 0.  The caller may cache the re-laid weight: see miq_transpose_i8.
+ */
+size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K);
+int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst[c,r] = src[r,c] for an int8 matrix src[rows, cols] (both dense).  Used to turn the
+ * [K,N] weight of linear_w8a8 into the [N,K] layout once, ahead of repeated GEMMs. */
+int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream);
+
+/* int8 Conv2d as an implicit GEMM, NCHW activations, OIHW weights, NCHW output.
+ *
+ * Replaces conv2d_int8(input, kernel, output, stride, padding)
+ * (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:81-114; kernel :6-78) when out_dtype = MIQ_I32,
+ * and the weight-only / weight+activation Conv2d forward (quant/Weight_Only/Quantizer.py:72-86,
+ * quant/Weight_Activation/Quantizer.py:53-60) with the epilogue of miq_gemm_i8 applied per
+ * output channel.  Output size Ho = (H + 2*pad - KH)/stride + 1 (conv2d_w8a8.cu:91-92); the
+ * input index is y*stride + i - pad as in F.conv2d (the reference kernel's inner loop drops
+ * the stride; its own test compares with F.conv2d).  Dilation 1, groups 1, square stride
+ * and padding, as the reference kernel.
+ * workspace: at least miq_conv2d_i8_workspace(...) bytes, 256-byte aligned: holds the
+ * zero-padded channels-last copy of x and the re-laid weight.
+ */
+size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                               int64_t KW, int64_t stride, int64_t pad);
+int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                  int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                  const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIQ_H */

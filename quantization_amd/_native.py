@@ -1,0 +1,242 @@
+"""ctypes binding of libmiq.so, the C-ABI library holding the HIP kernels (include/miq.h).
+
+PyTorch is used for device memory and streams only: tensors are allocated with torch, and
+their data pointers plus torch's current HIP stream are handed to the C entry points.
+There is no CPU implementation behind these functions: without the library or without a
+GPU they raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiq.so")
+
+MIQ_F32, MIQ_F16, MIQ_BF16, MIQ_I32 = 0, 1, 2, 3
+MIQ_W_NK, MIQ_W_KN = 0, 1
+
+_FLOAT_CODES = {torch.float32: MIQ_F32, torch.float16: MIQ_F16, torch.bfloat16: MIQ_BF16}
+_OUT_CODES = {torch.float32: MIQ_F32, torch.bfloat16: MIQ_BF16, torch.int32: MIQ_I32}
+
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+_int = ctypes.c_int
+_size = ctypes.c_size_t
+
+SYMBOLS = {
+    # name: (restype, argtypes)
+    "miq_version": (_int, []),
+    "miq_last_error": (ctypes.c_char_p, []),
+    "miq_quantize_rows_sym_i8": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _p, _p]),
+    "miq_row_max": (_int, [_p, _int, _i64, _i64, _p, _p]),
+    "miq_quantize_rows_given_i8": (_int, [_p, _int, _i64, _i64, _p, _p, _int, _p, _p]),
+    "miq_dequantize_channels_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "miq_dequantize_rows_i8": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "miq_gemm_i8_workspace": (_size, [_int, _i64, _i64, _i64]),
+    "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
+    "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
+    "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m quantization_amd.build` "
+                "(the quantization hot path has no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"miq error {rc}: {lib().miq_last_error().decode()}")
+
+
+def _stream():
+    return _p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return _p(t.data_ptr()) if t is not None else _p(0)
+
+
+def require_device(t, name):
+    """Same checks, same wording, as CHECK_INPUT in the reference's linear_w8a8.cpp:7-9."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _f32_vec(t, n, name, device):
+    if t is None:
+        return None
+    t = t.detach().reshape(-1)
+    if t.numel() != n:
+        raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def quantize_rows_sym_i8(w, want_row_max=False):
+    """w: [N, ...] float tensor on the GPU -> (q int8 like w, scale fp32 [N], zp int64 [N][, row_max])."""
+    require_device(w, "tensor")
+    if w.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"unsupported weight dtype {w.dtype}")
+    if w.dim() < 1:
+        raise RuntimeError("tensor must have at least one dimension")
+    rows = w.shape[0]
+    cols = w.numel() // rows if rows else 0
+    q = torch.empty(w.shape, dtype=torch.int8, device=w.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=w.device)
+    zp = torch.empty(rows, dtype=torch.int64, device=w.device)
+    row_max = torch.empty(rows, dtype=torch.float32, device=w.device) if want_row_max else None
+    with torch.cuda.device(w.device):
+        _check(lib().miq_quantize_rows_sym_i8(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(q), _ptr(scale),
+                                              _ptr(zp), _ptr(row_max), _stream()))
+    return (q, scale, zp, row_max) if want_row_max else (q, scale, zp)
+
+
+def row_max(w):
+    """Signed maximum of every w[n, ...] as fp32 [N]."""
+    require_device(w, "tensor")
+    rows = w.shape[0]
+    cols = w.numel() // rows if rows else 0
+    out = torch.empty(rows, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().miq_row_max(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(out), _stream()))
+    return out
+
+
+def quantize_rows_given_i8(w, scale, zp=None):
+    """q = int8(clamp(rint(w / scale + zp))) with scale/zp of `rows` entries or one."""
+    require_device(w, "tensor")
+    rows = w.shape[0]
+    cols = w.numel() // rows if rows else 0
+    scale = scale.detach().reshape(-1).to(device=w.device, dtype=torch.float32).contiguous()
+    if scale.numel() not in (1, rows):
+        raise RuntimeError(f"scales must have 1 or {rows} entries, got {scale.numel()}")
+    per_row = int(scale.numel() == rows and rows != 1)
+    if zp is not None:
+        zp = zp.detach().reshape(-1).to(device=w.device, dtype=torch.float32).contiguous()
+        if zp.numel() != scale.numel():
+            raise RuntimeError("zero_point and scales must have the same number of entries")
+    q = torch.empty(w.shape, dtype=torch.int8, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().miq_quantize_rows_given_i8(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(scale), _ptr(zp),
+                                                per_row, _ptr(q), _stream()))
+    return q
+
+
+def dequantize_channels_f32(y, scale, zp=None):
+    """scale[c] * (y - zp[c]) along axis 1 of a float32 tensor y."""
+    require_device(y, "quantized_tensor")
+    y = y.to(torch.float32)
+    outer, channels = y.shape[0], y.shape[1]
+    inner = y.numel() // max(outer * channels, 1)
+    scale = _f32_vec(scale, channels, "scales", y.device)
+    zp = _f32_vec(zp, channels, "zero_point", y.device)
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        _check(lib().miq_dequantize_channels_f32(_ptr(y), _ptr(scale), _ptr(zp), outer, channels, inner, _ptr(out),
+                                                 _stream()))
+    return out
+
+
+def dequantize_rows_i8(q, scale, zp=None):
+    require_device(q, "quantized_tensor")
+    rows = q.shape[0]
+    cols = q.numel() // rows if rows else 0
+    scale = _f32_vec(scale, rows, "scales", q.device)
+    if zp is not None:
+        zp = zp.detach().reshape(-1).to(device=q.device, dtype=torch.int64).contiguous()
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(lib().miq_dequantize_rows_i8(_ptr(q), _ptr(scale), _ptr(zp), rows, cols, _ptr(out), _stream()))
+    return out
+
+
+def transpose_i8(src):
+    require_device(src, "src")
+    rows, cols = src.shape
+    dst = torch.empty((cols, rows), dtype=torch.int8, device=src.device)
+    with torch.cuda.device(src.device):
+        _check(lib().miq_transpose_i8(_ptr(src), rows, cols, _ptr(dst), _stream()))
+    return dst
+
+
+def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
+    """out[m,n] = (float(sum_k a[m,k]*w[n,k]) + bias[n]) * alpha[n] + beta, or the raw int32 sums."""
+    require_device(a, "input")
+    require_device(w, "weights")
+    if a.dtype != torch.int8 or w.dtype != torch.int8:
+        raise RuntimeError(f"input and weights must be int8 (got {a.dtype}, {w.dtype})")
+    if a.dim() != 2 or w.dim() != 2:
+        raise RuntimeError("input and weights must be 2-D")
+    M, K = a.shape
+    if w_layout == MIQ_W_NK:
+        N, Kw = w.shape
+    else:
+        Kw, N = w.shape
+    if K != Kw:
+        raise RuntimeError(f"shape mismatch: input is [{M},{K}], weights contract over {Kw}")
+    if out_dtype not in _OUT_CODES:
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    bias = _f32_vec(bias, N, "bias", a.device)
+    alpha = _f32_vec(alpha, N, "alpha", a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    else:
+        require_device(out, "out")
+        if out.shape != (M, N) or out.dtype != out_dtype:
+            raise RuntimeError("out has the wrong shape or dtype")
+    L = lib()
+    need = L.miq_gemm_i8_workspace(w_layout, M, N, K)
+    ws = torch.empty(need, dtype=torch.int8, device=a.device) if need else None
+    with torch.cuda.device(a.device):
+        _check(L.miq_gemm_i8(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
+                             _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out
+
+
+def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
+    """NCHW int8 x, OIHW int8 w -> NCHW out with the per-channel epilogue of gemm_i8."""
+    require_device(x, "input")
+    require_device(w, "kernel")
+    if x.dtype != torch.int8 or w.dtype != torch.int8:
+        raise RuntimeError(f"input and kernel must be int8 (got {x.dtype}, {w.dtype})")
+    if x.dim() != 4 or w.dim() != 4:
+        raise RuntimeError("input and kernel must be 4-D (NCHW / OIHW)")
+    B, C, H, W = x.shape
+    Co, Ci, KH, KW = w.shape
+    if C != Ci:
+        raise RuntimeError(f"shape mismatch: input has {C} channels, kernel expects {Ci}")
+    if out_dtype not in _OUT_CODES:
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    Ho = (H + 2 * padding - KH) // stride + 1
+    Wo = (W + 2 * padding - KW) // stride + 1
+    if Ho <= 0 or Wo <= 0:
+        raise RuntimeError("kernel larger than the padded input")
+    bias = _f32_vec(bias, Co, "bias", x.device)
+    alpha = _f32_vec(alpha, Co, "alpha", x.device)
+    if out is None:
+        out = torch.empty((B, Co, Ho, Wo), dtype=out_dtype, device=x.device)
+    L = lib()
+    need = L.miq_conv2d_i8_workspace(B, C, H, W, Co, KH, KW, stride, padding)
+    ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(L.miq_conv2d_i8(_ptr(x), _ptr(w), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
+                               float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out

@@ -1,0 +1,44 @@
+// Shared host-side helpers for the miq C ABI (error text, argument checks, launch check).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "miq.h"
+
+namespace miq {
+
+// Thread-local message behind miq_last_error().
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// hipGetLastError() after a launch -> MIQ_ELAUNCH with the runtime's text.
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MIQ_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MIQ_OK;
+}
+
+// Dynamic LDS above 64 KiB has to be opted into per kernel (and per device); cheap to repeat.
+inline int allow_lds(const void* kernel, int bytes) {
+    if (bytes <= 64 * 1024) return MIQ_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(MIQ_ELAUNCH, "hipFuncSetAttribute(LDS=%d): %s", bytes, hipGetErrorString(e));
+    return MIQ_OK;
+}
+
+#define MIQ_REQUIRE(cond, code, ...)                  \
+    do {                                              \
+        if (!(cond)) return ::miq::fail(code, __VA_ARGS__); \
+    } while (0)
+
+}  // namespace miq

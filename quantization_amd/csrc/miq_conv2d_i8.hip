@@ -1,0 +1,385 @@
+// int8 Conv2d as an implicit GEMM on CDNA4 MFMA, NCHW in / OIHW weights / NCHW out.
+//
+//   M = B*Ho*Wo (output pixels), N = Cout, K = KH * KW * Cin.
+//
+// Two cheap re-layout passes make every MFMA operand K-contiguous:
+//   * activations: NCHW -> zero-padded channels-last xp[B][H+2p][W+2p][Cp] (Cp = Cin rounded
+//     up to 4).  For one output pixel and one filter row kh, the KW*Cp bytes it needs are then
+//     one contiguous run starting at xp[b][ho*s+kh][wo*s][0]: no bounds checks, no gather.
+//   * weights: OIHW -> wp[Cout][KH][Lp], Lp = KW*Cp rounded up to 16, zero where padded.  The
+//     zero weights cancel whatever the activation run holds past KW*Cp.
+// K is walked in 16-byte chunks; a small LDS table maps chunk -> byte offset inside xp
+// relative to the pixel's base.  The main loop is the GEMM's: 128-byte K-tiles, LDS-DMA
+// staging, double buffering, v_mfma_i32_16x16x64_i8.  Pixels are the MFMA's first operand,
+// so a lane holds four consecutive pixels of one output channel: a 16-byte NCHW store.
+//
+// Replaces conv2d_kernel_int8 / conv2d_int8 (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:6-114).
+#include "miq_common.h"
+#include "miq_gemm_core.h"
+
+namespace {
+
+using namespace miq;
+
+constexpr int kCinAlign = 4;
+
+struct ConvGeom {
+    int64_t B, Cin, H, W, Cout, KH, KW, stride, pad;
+    int64_t Ho, Wo, Hp, Wp, Cp, L, Lp, Kp, M;
+    int64_t xp_bytes, wp_bytes;
+};
+
+bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+               int64_t pad, ConvGeom& g) {
+    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    g.Hp = H + 2 * pad;
+    g.Wp = W + 2 * pad;
+    if (g.Hp < KH || g.Wp < KW) return false;
+    g.Ho = (g.Hp - KH) / stride + 1;  // conv2d_w8a8.cu:91-92
+    g.Wo = (g.Wp - KW) / stride + 1;
+    g.Cp = round_up(Cin, kCinAlign);
+    g.L = KW * g.Cp;
+    g.Lp = round_up(g.L, kChunk);
+    g.Kp = KH * g.Lp;
+    g.M = B * g.Ho * g.Wo;
+    g.xp_bytes = B * g.Hp * g.Wp * g.Cp;
+    g.wp_bytes = Cout * g.Kp;
+    return true;
+}
+
+// NCHW -> zero-padded NHWC.  One workgroup moves a 64-pixel x 64-channel block through LDS.
+__global__ __launch_bounds__(256) void nhwc_pad_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin,
+                                                       int H, int W, int Hp, int Wp, int Cp, int pad, int cblocks) {
+    __shared__ int8_t tile[64][68];
+    const int w0 = (blockIdx.x / cblocks) * 64, c0 = (blockIdx.x % cblocks) * 64;
+    const int hp = blockIdx.y, b = blockIdx.z;
+    const int h = hp - pad;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256, c = idx >> 6, wl = idx & 63;
+        const int w = w0 + wl - pad;
+        int8_t v = 0;
+        if (c0 + c < Cin && h >= 0 && h < H && w >= 0 && w < W)
+            v = x[((static_cast<int64_t>(b) * Cin + c0 + c) * H + h) * W + w];
+        tile[c][wl] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * 256, wl = idx >> 4, cw = (idx & 15) * 4;
+        if (w0 + wl < Wp && c0 + cw < Cp) {
+            const uint32_t v = (static_cast<uint32_t>(static_cast<uint8_t>(tile[cw][wl]))) |
+                               (static_cast<uint32_t>(static_cast<uint8_t>(tile[cw + 1][wl])) << 8) |
+                               (static_cast<uint32_t>(static_cast<uint8_t>(tile[cw + 2][wl])) << 16) |
+                               (static_cast<uint32_t>(static_cast<uint8_t>(tile[cw + 3][wl])) << 24);
+            *reinterpret_cast<uint32_t*>(xp + ((static_cast<int64_t>(b) * Hp + hp) * Wp + w0 + wl) * Cp + c0 + cw) = v;
+        }
+    }
+}
+
+// OIHW -> wp[Cout][KH][Lp] with (kw, c) order inside a filter row and zero fill.
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
+                                                               int64_t total, int Cin, int KH, int KW, int Cp, int L,
+                                                               int Lp) {
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int l = static_cast<int>(idx % Lp);
+        const int kh = static_cast<int>((idx / Lp) % KH);
+        const int64_t n = idx / (static_cast<int64_t>(Lp) * KH);
+        int8_t v = 0;
+        if (l < L) {
+            const int kw = l / Cp, c = l % Cp;
+            if (c < Cin) v = w[((n * Cin + c) * KH + kh) * KW + kw];
+        }
+        wp[idx] = v;
+    }
+}
+
+struct ConvArgs {
+    const int8_t* xp;
+    const int8_t* wp;
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int M, Cout, Kp;          // GEMM dims
+    int HoWo, Wo;             // pixel decomposition
+    int img_stride;           // Hp*Wp*Cp, bytes per image in xp
+    int row_stride;           // Wp*Cp
+    int sx;                   // stride*Cp: bytes between horizontally adjacent output pixels' windows
+    int sy;                   // stride*Wp*Cp
+    int cps;                  // 16-byte chunks per filter row (Lp / 16)
+    uint32_t xp_bytes, wp_bytes;
+    int tiles_m, tiles_n;
+};
+
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nrows, int K, int kt,
+                                           int wave, int lane) {
+    constexpr int kPieces = ROWS / 8;
+    constexpr int kIters = (kPieces + NWAVES - 1) / NWAVES;
+    const int r_in = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < kIters; ++i) {
+        const int piece = wave + i * NWAVES;
+        if (kPieces % NWAVES != 0 && piece >= kPieces) break;
+        const int r = piece * 8 + r_in;
+        const int c = slot ^ ((r >> 1) & 7);
+        const int k = kt * kTileK + c * kChunk;
+        const int row = row0 + r;
+        const uint32_t off =
+            (row < nrows && k < K) ? static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + k : kOob;
+        dma16(rsrc, tile + piece * (8 * kTileK), off);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArgs g) {
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int STAGE = (BM + BN) * kTileK;
+    constexpr int kPiecesM = BM / 8;
+    constexpr int kItersM = (kPiecesM + NWAVES - 1) / NWAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* table = reinterpret_cast<int*>(smem + 2 * STAGE);  // chunk -> byte offset from the pixel base
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nchunks = g.Kp / kChunk;
+    for (int q = threadIdx.x; q < nchunks; q += 64 * NWAVES) table[q] = (q / g.cps) * g.row_stride + (q % g.cps) * kChunk;
+
+    // Base offset in xp of the pixel each of this lane's staging rows belongs to.
+    const int r_in = lane >> 3, slot = lane & 7;
+    uint32_t pix[kItersM];
+#pragma unroll
+    for (int i = 0; i < kItersM; ++i) {
+        const int m = m0 + (wave + i * NWAVES) * 8 + r_in;
+        if (m < g.M) {
+            const int b = m / g.HoWo, p = m % g.HoWo;
+            pix[i] = static_cast<uint32_t>(b) * g.img_stride + (p / g.Wo) * g.sy + (p % g.Wo) * g.sx;
+        } else {
+            pix[i] = kOob;
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+
+    v4i acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    __syncthreads();  // table visible
+
+    auto stage_pixels = [&](char* tile, int kt) {
+#pragma unroll
+        for (int i = 0; i < kItersM; ++i) {
+            const int piece = wave + i * NWAVES;
+            if (kPiecesM % NWAVES != 0 && piece >= kPiecesM) break;
+            const int r = piece * 8 + r_in;
+            const int q = kt * kChunksPerRow + (slot ^ ((r >> 1) & 7));
+            uint32_t off = kOob;
+            if (q < nchunks && pix[i] != kOob) off = pix[i] + table[q];
+            dma16(rx, tile + piece * (8 * kTileK), off);
+        }
+    };
+
+    const int nt = (g.Kp + kTileK - 1) / kTileK;
+    const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
+
+    stage_pixels(smem, 0);
+    stage_rows<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.Cout, g.Kp, 0, wave, lane);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        if (t + 1 < nt) {
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            stage_pixels(nxt, t + 1);
+            stage_rows<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.Cout, g.Kp, t + 1, wave, lane);
+        }
+        const char* at = cur + wm * WM * kTileK;
+        const char* wt = cur + BM * kTileK + wn * WN * kTileK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int lo = ks ? lo1 : lo0;
+            v4i wf[FN], af[FM];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wt + j * 16 * kTileK + lo);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = lds_read16(at + i * 16 * kTileK + lo);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  D[i][j]: i = 4*(lane>>4) + reg -> pixel, j = lane&15 -> output channel.
+    const int mbase = m0 + wm * WM + (lane >> 4) * 4;
+    const int nbase = n0 + wn * WN + (lane & 15);
+    const bool vec_ok = (g.HoWo & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nbase + j * 16;
+        if (n >= g.Cout) continue;
+        float al = 1.f, bi = 0.f;
+        if constexpr (OUT != kOutI32) {
+            al = g.alpha[n];
+            if (g.bias) bi = g.bias[n];
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mbase + i * 16;
+            if (m >= g.M) continue;
+            const v4i a = acc[i][j];
+            if (vec_ok) {  // m % 4 == 0 and HoWo % 4 == 0: the four pixels share an image
+                const int b = m / g.HoWo, p = m % g.HoWo;
+                const size_t idx = (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + p;
+                if constexpr (OUT == kOutI32) {
+                    *reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx) = a;
+                } else if constexpr (OUT == kOutF32) {
+                    *reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx) =
+                        v4f{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                            dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta)};
+                } else {
+                    uint2 pk;
+                    pk.x = f32_to_bf16_bits(dequant1(a[0], bi, al, g.beta)) |
+                           (static_cast<uint32_t>(f32_to_bf16_bits(dequant1(a[1], bi, al, g.beta))) << 16);
+                    pk.y = f32_to_bf16_bits(dequant1(a[2], bi, al, g.beta)) |
+                           (static_cast<uint32_t>(f32_to_bf16_bits(dequant1(a[3], bi, al, g.beta))) << 16);
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int me = m + e;
+                    if (me >= g.M) break;
+                    const int b = me / g.HoWo, p = me % g.HoWo;
+                    const size_t idx = (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + p;
+                    if constexpr (OUT == kOutI32) {
+                        static_cast<int*>(g.out)[idx] = a[e];
+                    } else if constexpr (OUT == kOutF32) {
+                        static_cast<float*>(g.out)[idx] = dequant1(a[e], bi, al, g.beta);
+                    } else {
+                        static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(dequant1(a[e], bi, al, g.beta));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+int launch_tile(ConvArgs g, hipStream_t st) {
+    g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
+    g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
+    const int lds = 2 * (BM + BN) * kTileK + static_cast<int>(round_up(g.Kp / kChunk * 4, 16));
+    auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
+    return check_launch("conv_i8_kernel");
+}
+
+template <int OUT>
+int launch(const ConvArgs& g, hipStream_t st) {
+    // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
+    auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
+    if (g.Cout > 128 && tiles(256, 256) >= 200) return launch_tile<256, 256, 2, 4, OUT>(g, st);
+    if (g.Cout > 64 && tiles(256, 128) >= 200) return launch_tile<256, 128, 2, 4, OUT>(g, st);
+    if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
+    if (g.Cout > 64) return launch_tile<128, 128, 2, 2, OUT>(g, st);
+    return launch_tile<128, 64, 2, 2, OUT>(g, st);
+}
+
+}  // namespace
+
+extern "C" size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                                          int64_t KW, int64_t stride, int64_t pad) {
+    ConvGeom g;
+    if (!make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, g)) return 0;
+    return static_cast<size_t>(miq::round_up(g.xp_bytes, 256) + miq::round_up(g.wp_bytes, 256));
+}
+
+extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    ConvGeom G;
+    MIQ_REQUIRE(make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G), MIQ_EINVAL,
+                "miq_conv2d_i8: bad geometry (B=%lld Cin=%lld H=%lld W=%lld Cout=%lld KH=%lld KW=%lld stride=%lld pad=%lld)",
+                (long long)B, (long long)Cin, (long long)H, (long long)W, (long long)Cout, (long long)KH,
+                (long long)KW, (long long)stride, (long long)pad);
+    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32, MIQ_EINVAL,
+                "miq_conv2d_i8: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", out_dtype);
+    if (G.M == 0 || Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(x && w && out, MIQ_EINVAL, "miq_conv2d_i8: null pointer");
+    MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "miq_conv2d_i8: alpha is required for a dequantised output");
+    MIQ_REQUIRE(G.xp_bytes < (1ll << 31) && G.wp_bytes < (1ll << 31) && G.M < (1ll << 31) && B < 65536 && G.Hp < 65536,
+                MIQ_ERANGE, "miq_conv2d_i8: padded activations (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)G.xp_bytes, (long long)G.wp_bytes);
+    MIQ_REQUIRE(G.Kp / kChunk <= 4096, MIQ_ERANGE, "miq_conv2d_i8: KH*KW*Cin too large (%lld > 65536)", (long long)G.Kp);
+    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(miq::aligned(out, 4 * esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
+                "miq_conv2d_i8: out must be 16-byte (8 for bf16) aligned, alpha/bias 4-byte aligned");
+    const size_t need = miq_conv2d_i8_workspace(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                "miq_conv2d_i8: needs %zu bytes of workspace (got %zu)", need, workspace_bytes);
+    MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_i8: workspace must be 256-byte aligned");
+    hipStream_t st = miq::as_stream(stream);
+
+    int8_t* xp = static_cast<int8_t*>(workspace);
+    int8_t* wp = xp + miq::round_up(G.xp_bytes, 256);
+    {
+        const int cblocks = static_cast<int>(miq::ceil_div(G.Cp, 64));
+        dim3 grid(static_cast<unsigned>(miq::ceil_div(G.Wp, 64) * cblocks), static_cast<unsigned>(G.Hp),
+                  static_cast<unsigned>(B));
+        nhwc_pad_kernel<<<grid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp,
+                                              (int)pad, cblocks);
+        if (int rc = miq::check_launch("nhwc_pad_kernel")) return rc;
+        const int64_t total = G.wp_bytes;
+        const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+        pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
+                                                       (int)G.Lp);
+        if (int rc = miq::check_launch("pack_conv_weight_kernel")) return rc;
+    }
+
+    ConvArgs a{};
+    a.xp = xp;
+    a.wp = wp;
+    a.bias = bias;
+    a.alpha = alpha;
+    a.out = out;
+    a.beta = beta;
+    a.M = static_cast<int>(G.M);
+    a.Cout = static_cast<int>(Cout);
+    a.Kp = static_cast<int>(G.Kp);
+    a.HoWo = static_cast<int>(G.Ho * G.Wo);
+    a.Wo = static_cast<int>(G.Wo);
+    a.img_stride = static_cast<int>(G.Hp * G.Wp * G.Cp);
+    a.row_stride = static_cast<int>(G.Wp * G.Cp);
+    a.sx = static_cast<int>(stride * G.Cp);
+    a.sy = static_cast<int>(stride * G.Wp * G.Cp);
+    a.cps = static_cast<int>(G.Lp / kChunk);
+    a.xp_bytes = static_cast<uint32_t>(G.xp_bytes);
+    a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
+    switch (out_dtype) {
+        case MIQ_F32:
+            return launch<kOutF32>(a, st);
+        case MIQ_BF16:
+            return launch<kOutBF16>(a, st);
+        default:
+            return launch<kOutI32>(a, st);
+    }
+}

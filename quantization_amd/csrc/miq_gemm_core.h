@@ -1,0 +1,91 @@
+// Device-side building blocks shared by the int8 GEMM and the implicit-GEMM conv:
+// LDS tile geometry, the bank-conflict-free swizzle, LDS-DMA staging, MFMA fragment reads
+// and the per-channel dequant epilogue.
+//
+// Geometry.  Both operands are K-contiguous int8 rows.  A K-tile is 128 bytes deep, so an
+// LDS tile is `rows` x 128 B, cut in 16-byte chunks (8 per row).  `v_mfma_i32_16x16x64_i8`
+// takes 16 bytes per lane per operand: lane l supplies row (l & 15) and the 16-byte chunk
+// (l >> 4) of a 64-deep k-step, for both operands alike, so the k order inside the
+// instruction never has to be known: both operands use the same chunk -> lane map and an
+// integer sum does not depend on its order.
+//
+// Swizzle.  `ds_read_b128` is served in 16-lane groups over a 256-byte bank row, i.e. 16
+// chunk slots shared by two 128-byte tile rows.  Chunk c of row r is stored at slot
+// c ^ ((r >> 1) & 7) of its row, which makes every group of a fragment read hit 16
+// different slots.  LDS-DMA writes LDS linearly (wave base + lane * 16), so the swizzle is
+// applied to the per-lane SOURCE address when staging and again to the read address.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace miq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kTileK = 128;                 // bytes (= int8 elements) per K-tile
+constexpr int kChunk = 16;                  // bytes per LDS-DMA piece / MFMA operand per lane
+constexpr int kChunksPerRow = kTileK / kChunk;
+constexpr uint32_t kOob = 0x80000000u;      // buffer offset that is always out of range (-> reads 0)
+
+using lds_ptr = __attribute__((address_space(3))) void*;
+
+// Raw buffer resource over `bytes` bytes at p (bytes < 2^31).  Loads past the end return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// 16 bytes global -> LDS, no register staging.  `dst` is the wave's base (lane l lands at
+// dst + 16*l); `voffset` is this lane's byte offset into the buffer (kOob -> zeros).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, uint32_t voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voffset, 0, 0, 0);
+}
+
+// Byte offset, inside a rows x 128 B tile, of logical chunk `c` (0..7) of row `r`.
+__device__ __forceinline__ int tile_offset(int r, int c) {
+    return r * kTileK + ((c ^ ((r >> 1) & 7)) * kChunk);
+}
+
+// Per-lane part of a fragment read address for k-step ks (0 or 1) of a K-tile.  The fragment's
+// first row must be a multiple of 16, so the swizzle term depends on the lane only.
+__device__ __forceinline__ int frag_lane_offset(int lane, int ks) {
+    const int r = lane & 15;
+    const int c = ks * 4 + (lane >> 4);
+    return r * kTileK + ((c ^ (r >> 1)) * kChunk);
+}
+
+__device__ __forceinline__ v4i lds_read16(const char* p) { return *reinterpret_cast<const v4i*>(p); }
+
+// XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs, so
+// ids b, b+8, ... share an L2.  Give each XCD a contiguous range of tile ids (bijective for
+// any grid size), then walk that range in bands of `group` tile-rows so that the tiles in
+// flight on one XCD share operand panels.
+__device__ __forceinline__ void tile_coords(int pid, int nwg, int tiles_m, int tiles_n, int group, int& tm,
+                                            int& tn) {
+    const int q = nwg / 8, r = nwg % 8, xcd = pid % 8;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pid / 8;
+    const int band = group * tiles_n;
+    const int first_m = (id / band) * group;
+    const int gsz = tiles_m - first_m < group ? tiles_m - first_m : group;
+    const int in_band = id % band;
+    tm = first_m + in_band % gsz;
+    tn = in_band / gsz;
+}
+
+enum : int { kOutF32 = 0, kOutBF16 = 2, kOutI32 = 3 };  // == MIQ_F32 / MIQ_BF16 / MIQ_I32
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+
+// (float(acc) + bias) * alpha + beta with one rounding per step (no contraction), the order
+// the reference's Python applies: Weight_Only/Quantizer.py:79-86, Weight_Activation/Quantizer.py:58-60.
+__device__ __forceinline__ float dequant1(int acc, float bias, float alpha, float beta) {
+    return __fadd_rn(__fmul_rn(__fadd_rn(static_cast<float>(acc), bias), alpha), beta);
+}
+
+}  // namespace miq

@@ -1,0 +1,308 @@
+// int8 x int8 -> int32 GEMM on CDNA4 MFMA (v_mfma_i32_16x16x64_i8) with a fused per-channel
+// dequant epilogue:  out[m,n] = (float(sum_k A[m,k] * W[n,k]) + bias[n]) * alpha[n] + beta.
+//
+// Both operands are K-contiguous (A [M,K], W [N,K]).  A workgroup owns a BM x BN output
+// tile and walks K in 128-byte tiles, double-buffered in LDS and filled by LDS-DMA
+// (buffer_load ... lds, 16 B per lane, zero-filled past the matrix edges by the buffer
+// range check).  The weight tile is the MFMA's first operand and the activation tile the
+// second, so a lane's four accumulator registers are four consecutive output channels of
+// one output row: the epilogue loads alpha/bias as one 16-byte vector and stores 16 bytes.
+//
+// Replaces linear_w8a8_kernel (cuda_kernels/linear_int8/linear_w8a8_kernel.cu:5-22) and the
+// dequantisation the reference's Python applies after its matmul (see include/miq.h).
+#include "miq_common.h"
+#include "miq_gemm_core.h"
+
+namespace {
+
+using namespace miq;
+
+struct GemmArgs {
+    const int8_t* A;  // [M,K]
+    const int8_t* W;  // [N,K]
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+// Fills one LDS stage: rows [row0, row0 + ROWS) x K-tile kt of a [nrows, K] int8 matrix.
+// Each wave-instruction moves 8 rows x 128 B; the chunk a lane fetches is the one its LDS
+// slot must hold under the swizzle.
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nrows, int K,
+                                           int kt, int wave, int lane) {
+    static_assert(ROWS % 8 == 0, "a piece is 8 rows");
+    constexpr int kPieces = ROWS / 8;
+    constexpr int kIters = (kPieces + NWAVES - 1) / NWAVES;
+    const int r_in = lane >> 3;      // row within the 8-row piece
+    const int slot = lane & 7;       // chunk slot within the row
+#pragma unroll
+    for (int i = 0; i < kIters; ++i) {
+        const int piece = wave + i * NWAVES;  // wave-uniform
+        if (kPieces % NWAVES != 0 && piece >= kPieces) break;
+        const int r = piece * 8 + r_in;
+        const int c = slot ^ ((r >> 1) & 7);
+        const int k = kt * kTileK + c * kChunk;
+        const int row = row0 + r;
+        const uint32_t off = (row < nrows && k < K) ? static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + k
+                                                    : kOob;
+        dma16(rsrc, tile + piece * (8 * kTileK), off);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArgs g) {
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave output tile
+    constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
+    constexpr int STAGE = (BM + BN) * kTileK;            // bytes per pipeline stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, static_cast<uint32_t>(g.M) * g.K);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+
+    v4i acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    const int nt = (g.K + kTileK - 1) / kTileK;
+    const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
+
+    stage_tile<BM, NWAVES>(ra, smem, m0, g.M, g.K, 0, wave, lane);
+    stage_tile<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.N, g.K, 0, wave, lane);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        if (t + 1 < nt) {
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            stage_tile<BM, NWAVES>(ra, nxt, m0, g.M, g.K, t + 1, wave, lane);
+            stage_tile<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.N, g.K, t + 1, wave, lane);
+        }
+        const char* at = cur + wm * WM * kTileK;
+        const char* wt = cur + BM * kTileK + wn * WN * kTileK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int lo = ks ? lo1 : lo0;
+            v4i wf[FN], af[FM];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wt + j * 16 * kTileK + lo);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = lds_read16(at + i * 16 * kTileK + lo);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // stage t+1 landed (LDS-DMA drained) and stage t fully read
+    }
+
+    // Epilogue.  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
+    const int mrow = m0 + wm * WM + (lane & 15);
+    const int ncol = n0 + wn * WN + (lane >> 4) * 4;
+    const bool vec_ok = (g.N & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = ncol + j * 16;
+        float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (OUT != kOutI32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) {
+                    al[e] = g.alpha[n + e];
+                    if (g.bias) bi[e] = g.bias[n + e];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mrow + i * 16;
+            if (m >= g.M || n >= g.N) continue;
+            const v4i a = acc[i][j];
+            const size_t idx = static_cast<size_t>(m) * g.N + n;
+            if constexpr (OUT == kOutI32) {
+                int* o = static_cast<int*>(g.out) + idx;
+                if (vec_ok && n + 3 < g.N) {
+                    *reinterpret_cast<v4i*>(o) = a;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) o[e] = a[e];
+                }
+            } else {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
+                if constexpr (OUT == kOutF32) {
+                    float* o = static_cast<float*>(g.out) + idx;
+                    if (vec_ok && n + 3 < g.N) {
+                        *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) o[e] = y[e];
+                    }
+                } else {
+                    uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
+                    if (vec_ok && n + 3 < g.N) {
+                        uint2 p;
+                        p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
+                        p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
+                        *reinterpret_cast<uint2*>(o) = p;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Any K and any alignment: one thread per output element.  Only shapes the MFMA path cannot
+// take (K not a multiple of 16, or misaligned pointers) come here; they are tiny layers.
+template <int OUT>
+__global__ __launch_bounds__(256) void gemm_i8_any_kernel(GemmArgs g) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int m = static_cast<int>(idx / g.N), n = static_cast<int>(idx % g.N);
+        const int8_t* a = g.A + static_cast<int64_t>(m) * g.K;
+        const int8_t* w = g.W + static_cast<int64_t>(n) * g.K;
+        int sum = 0;
+        for (int k = 0; k < g.K; ++k) sum += static_cast<int>(a[k]) * static_cast<int>(w[k]);
+        if constexpr (OUT == kOutI32) {
+            static_cast<int*>(g.out)[idx] = sum;
+        } else {
+            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
+            if constexpr (OUT == kOutF32) {
+                static_cast<float*>(g.out)[idx] = y;
+            } else {
+                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_i8_kernel(const int8_t* __restrict__ src, int64_t rows,
+                                                           int64_t cols, int8_t* __restrict__ dst) {
+    __shared__ int8_t tile[64][65];
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64, c0 = static_cast<int64_t>(blockIdx.x) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;
+        if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(r0 + r) * cols + c0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;  // r: src column, c: src row
+        if (c0 + r < cols && r0 + c < rows) dst[(c0 + r) * rows + r0 + c] = tile[c][r];
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+int launch_tile(GemmArgs g, hipStream_t st) {
+    g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
+    g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
+    constexpr int kLds = 2 * (BM + BN) * kTileK;
+    auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
+    if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_gemm_i8: too many tiles");
+    kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
+    return check_launch("gemm_i8_kernel");
+}
+
+template <int OUT>
+int launch(GemmArgs g, bool mfma_ok, hipStream_t st) {
+    if (!mfma_ok) {
+        const int64_t total = static_cast<int64_t>(g.M) * g.N;
+        const int grid = static_cast<int>(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+        gemm_i8_any_kernel<OUT><<<grid, 256, 0, st>>>(g);
+        return check_launch("gemm_i8_any_kernel");
+    }
+    // Tile choice: the 256x256 tile (8 waves, 128 KiB LDS) once both dimensions can fill the
+    // chip with it; smaller tiles keep more workgroups in flight for thin problems.
+    const int64_t big_tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    if (g.M > 128 && big_tiles >= 192) return launch_tile<256, 256, 2, 4, OUT>(g, st);
+    if (g.M > 64) return launch_tile<128, 128, 2, 2, OUT>(g, st);
+    if (g.M > 32) return launch_tile<64, 64, 2, 2, OUT>(g, st);
+    if (g.M > 16) return launch_tile<32, 64, 1, 4, OUT>(g, st);
+    return launch_tile<16, 64, 1, 4, OUT>(g, st);
+}
+
+}  // namespace
+
+extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K) {
+    (void)M;
+    if (w_layout != MIQ_W_KN || N <= 0 || K <= 0) return 0;
+    return static_cast<size_t>(miq::round_up(N * K, 256));
+}
+
+extern "C" int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream) {
+    MIQ_REQUIRE(rows >= 0 && cols >= 0, MIQ_EINVAL, "miq_transpose_i8: negative size");
+    if (rows == 0 || cols == 0) return MIQ_OK;
+    MIQ_REQUIRE(src && dst, MIQ_EINVAL, "miq_transpose_i8: null pointer");
+    MIQ_REQUIRE(miq::ceil_div(rows, 64) < 65536, MIQ_ERANGE, "miq_transpose_i8: more than 4M rows");
+    dim3 grid(static_cast<unsigned>(miq::ceil_div(cols, 64)), static_cast<unsigned>(miq::ceil_div(rows, 64)));
+    transpose_i8_kernel<<<grid, 256, 0, miq::as_stream(stream)>>>(src, rows, cols, dst);
+    return miq::check_launch("transpose_i8_kernel");
+}
+
+extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                           const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "miq_gemm_i8: negative size (M=%lld N=%lld K=%lld)",
+                (long long)M, (long long)N, (long long)K);
+    MIQ_REQUIRE(w_layout == MIQ_W_NK || w_layout == MIQ_W_KN, MIQ_EINVAL, "miq_gemm_i8: unknown w_layout %d", w_layout);
+    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32, MIQ_EINVAL,
+                "miq_gemm_i8: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", out_dtype);
+    if (M == 0 || N == 0) return MIQ_OK;
+    MIQ_REQUIRE(out, MIQ_EINVAL, "miq_gemm_i8: null output");
+    MIQ_REQUIRE(K == 0 || (A && W), MIQ_EINVAL, "miq_gemm_i8: null operand");
+    MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "miq_gemm_i8: alpha is required for a dequantised output");
+    MIQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && M * K < (1ll << 31) && N * K < (1ll << 31),
+                MIQ_ERANGE, "miq_gemm_i8: operands are indexed with 31-bit byte offsets (M*K and N*K < 2^31)");
+    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
+                "miq_gemm_i8: out/alpha/bias not aligned to their element size");
+    hipStream_t st = miq::as_stream(stream);
+
+    if (w_layout == MIQ_W_KN && K > 0) {
+        const size_t need = miq_gemm_i8_workspace(w_layout, M, N, K);
+        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                    "miq_gemm_i8: [K,N] weights need %zu bytes of workspace (got %zu)", need, workspace_bytes);
+        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
+        int rc = miq_transpose_i8(W, K, N, static_cast<int8_t*>(workspace), stream);
+        if (rc != MIQ_OK) return rc;
+        W = static_cast<const int8_t*>(workspace);
+    }
+
+    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0};
+    // 16-byte vector stores in the epilogue need out rows 16-byte aligned when N % 4 == 0.
+    const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
+    const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(A, 16) && miq::aligned(W, 16) && out_vec_ok &&
+                         (out_dtype == MIQ_I32 || (miq::aligned(alpha, 4) && miq::aligned(bias, 4)));
+    switch (out_dtype) {
+        case MIQ_F32:
+            return launch<kOutF32>(g, mfma_ok, st);
+        case MIQ_BF16:
+            return launch<kOutBF16>(g, mfma_ok, st);
+        default:
+            return launch<kOutI32>(g, mfma_ok, st);
+    }
+}

@@ -1,0 +1,297 @@
+"""Parity of the HIP kernels, called through the C ABI (quantization_amd._native -> libmiq.so),
+against the CPU oracle and the golden fixtures produced by the reference.
+
+Bars: bit-exact for int8 weights, int64 zero points, fp32 scales and int32 accumulators;
+fp32 dequantised outputs bit-exact against the oracle's epilogue (same operation order) and
+within 1e-3 relative of the reference's own float outputs; bf16 outputs within one bf16 ulp.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, kind_of
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+QW = Golden("quantizer_wo.npz")
+FW = Golden("wo_forward.npz")
+WA = Golden("wa_chunker.npz")
+TORCH_KIND = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def N():
+    from quantization_amd import _native
+    _native.lib()
+    return _native
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------ quantizer
+@pytest.mark.parametrize("case", QW.cases())
+def test_quantizer_golden(N, case):
+    kind = kind_of(case)
+    w = dev(QW.get(case, "w"), TORCH_KIND[kind])
+    q, s, zp, rmax = N.quantize_rows_sym_i8(w, want_row_max=True)
+    ref_q, ref_s, ref_zp = QW.get(case, "q"), QW.get(case, "scales"), QW.get(case, "zp")
+    np.testing.assert_array_equal(q.cpu().numpy(), ref_q)
+    np.testing.assert_array_equal(s.cpu().numpy(), ref_s.reshape(-1))
+    np.testing.assert_array_equal(zp.cpu().numpy(), ref_zp.reshape(-1))
+    assert zp.dtype == torch.int64
+    np.testing.assert_array_equal(rmax.cpu().numpy(), O.row_signed_max(QW.get(case, "w")))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (7, 64), (5, 256), (130, 260), (9, 1024), (6, 2052),
+                                        (4, 4096), (3, 8192), (2, 16384), (2, 28672), (2, 40000), (2, 40001),
+                                        (1000, 36), (2049, 128)])
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_quantizer_vs_oracle_shapes(N, rows, cols, kind):
+    """Every dispatch branch (wave-per-row, workgroup-per-row at each register depth, the
+    streaming fallbacks, unaligned rows) in all three input precisions."""
+    g = torch.Generator().manual_seed(rows * 100003 + cols)
+    w = torch.randn(rows, cols, generator=g)
+    if rows > 2:
+        w[1] = -w[1].abs() - 1e-3
+        w[2] = 0
+    w = w.to(TORCH_KIND[kind])
+    q, s, zp = N.quantize_rows_sym_i8(w.cuda())
+    with np.errstate(over="ignore"):
+        rq, rs, rzp = O.quantize_channel_sym_int8(w.float().numpy(), kind=kind)
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs.reshape(-1))
+    assert int(zp.abs().sum()) == 0
+
+
+def test_quantizer_unaligned_base(N):
+    """A view that starts 4 bytes into an allocation takes the element-wise kernel."""
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn(1 + 12 * 64, generator=g).cuda()
+    w = buf[1:].view(12, 64)
+    q, s, _ = N.quantize_rows_sym_i8(w)
+    rq, rs, _ = O.quantize_channel_sym_int8(w.cpu().numpy())
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs.reshape(-1))
+
+
+def test_quantizer_ties_and_saturation(N):
+    """Half-way quotients (round-half-even), +-inf-sized quotients against the eps floor."""
+    w = torch.zeros(4, 256)
+    w[0] = torch.arange(-128, 128) * 0.5 + 0.0
+    w[0, 0] = 127.5                       # scale = 1 -> quotients are k/2: ties everywhere
+    w[1] = -torch.rand(256) * 1e30 - 1.0  # all negative: scale = eps, everything saturates at -128
+    w[2, 5] = 3e38                        # scale ~ 2.35e36
+    w[2, 6] = -3e38
+    w[3] = torch.rand(256) * 1e-12        # max below eps*127.5: floor applies, all round to 0
+    q, s, _ = N.quantize_rows_sym_i8(w.cuda())
+    rq, rs, _ = O.quantize_channel_sym_int8(w.numpy())
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs.reshape(-1))
+    assert (q[1] == -128).all() and float(s[1]) == 2.0 ** -23
+
+
+def test_quantizer_empty_and_errors(N):
+    q, s, zp = N.quantize_rows_sym_i8(torch.empty(0, 16).cuda())
+    assert q.shape == (0, 16) and s.numel() == 0
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        N.quantize_rows_sym_i8(torch.zeros(2, 2))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        N.quantize_rows_sym_i8(torch.zeros(4, 4).cuda().t())
+    with pytest.raises(RuntimeError, match="zero length"):
+        N.quantize_rows_sym_i8(torch.empty(3, 0).cuda())
+
+
+def test_row_max_given_and_dequant(N):
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(37, 301, generator=g)
+    wd = w.cuda()
+    np.testing.assert_array_equal(N.row_max(wd).cpu().numpy(), w.numpy().max(axis=1))
+    q, s, zp = N.quantize_rows_sym_i8(wd)
+    q2 = N.quantize_rows_given_i8(wd, s)
+    assert torch.equal(q, q2)
+    # per-tensor affine form: q = clamp(rint(w / s + zp))
+    sc, z = O.calculate_params_affine_tensor(w.min().item(), w.max().item())
+    q3 = N.quantize_rows_given_i8(wd, torch.from_numpy(sc), torch.from_numpy(z))
+    ref = np.clip(np.rint(w.numpy() / sc[0] + np.float32(z[0])), -128, 127).astype(np.int8)
+    np.testing.assert_array_equal(q3.cpu().numpy(), ref)
+    d = N.dequantize_rows_i8(q, s, zp)
+    np.testing.assert_array_equal(d.cpu().numpy(), O.dequantize(q.cpu().numpy(), s.cpu().numpy()[:, None], 0))
+    y = torch.randn(3, 37, 5, generator=g)
+    dz = N.dequantize_channels_f32(y.cuda(), s, None)
+    np.testing.assert_array_equal(dz.cpu().numpy(), (s.cpu().numpy()[None, :, None] * y.numpy()))
+
+
+# ------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [
+    (1, 64, 64), (3, 4, 16), (16, 64, 128), (17, 130, 48), (33, 100, 272), (64, 256, 512), (65, 72, 1040),
+    (128, 128, 128), (129, 257, 400), (200, 520, 384), (256, 256, 256), (300, 4096, 256), (512, 768, 1024),
+    (1024, 4096, 2048),  # the reference's own test shape (linear_int8/test.py:5-6)
+    (37, 130, 300), (3, 4, 6), (5, 48, 64),  # K not a multiple of 16 -> element-wise kernel
+]
+
+
+def rand_i8(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-128, 128, shape, generator=g, dtype=torch.int32).to(torch.int8)
+
+
+@pytest.mark.parametrize("M,N_,K", GEMM_SHAPES)
+def test_gemm_i32_bit_exact(N, M, N_, K):
+    a, w = rand_i8((M, K), M * 7 + K), rand_i8((N_, K), N_ * 13 + K)
+    ref = OC.linear_i8_nt(a.numpy(), w.numpy()) if M * N_ * K <= 2 ** 28 else \
+        O.linear_w8a8(a.numpy(), np.ascontiguousarray(w.numpy().T))
+    out = N.gemm_i8(a.cuda(), w.cuda(), out_dtype=torch.int32)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_gemm_extreme_values(N):
+    """All -128 x -128 at K = 8192: the largest accumulator the path can see."""
+    M, N_, K = 32, 64, 8192
+    a = torch.full((M, K), -128, dtype=torch.int8)
+    w = torch.full((N_, K), -128, dtype=torch.int8)
+    out = N.gemm_i8(a.cuda(), w.cuda(), out_dtype=torch.int32)
+    assert (out == 128 * 128 * K).all()
+    w[:, ::2] = 127
+    out = N.gemm_i8(a.cuda(), w.cuda(), out_dtype=torch.int32)
+    assert (out == (128 * 128 - 128 * 127) * (K // 2)).all()
+
+
+def test_gemm_lane_map_asymmetric(N):
+    """A = identity-like, W asymmetric: catches a transposed or permuted output tile."""
+    K = 256
+    a = torch.zeros(K, K, dtype=torch.int8)
+    a[torch.arange(K), torch.arange(K)] = 1
+    w = ((torch.arange(300)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 251 - 125).to(torch.int8)
+    out = N.gemm_i8(a.cuda(), w.cuda(), out_dtype=torch.int32)
+    np.testing.assert_array_equal(out.cpu().numpy(), w.numpy().T.astype(np.int32))
+
+
+@pytest.mark.parametrize("M,N_,K", [(5, 64, 64), (37, 130, 304), (256, 512, 1024), (300, 1027, 512), (8, 4, 6)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_gemm_epilogue_f32_bit_exact_vs_oracle(N, M, N_, K, with_bias):
+    a, w = rand_i8((M, K), 1 + M), rand_i8((N_, K), 2 + N_)
+    g = torch.Generator().manual_seed(3)
+    alpha = torch.rand(N_, generator=g) * 0.01 + 1e-4
+    bias = torch.randn(N_, generator=g) * 50 if with_bias else None
+    beta = 0.375
+    acc = O.linear_w8a8(a.numpy(), np.ascontiguousarray(w.numpy().T))
+    ref = OC.epilogue_f32(acc, None if bias is None else bias.numpy(), alpha.numpy(), beta)
+    out = N.gemm_i8(a.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(), alpha=alpha.cuda(), beta=beta)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # bf16 output: the same value rounded once to bf16
+    outb = N.gemm_i8(a.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(), alpha=alpha.cuda(), beta=beta,
+                     out_dtype=torch.bfloat16)
+    np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
+
+
+def test_gemm_kn_layout_is_linear_w8a8(N):
+    """[K,N] weights, raw int32 out: the linear_w8a8 contract."""
+    a, b = rand_i8((70, 96), 5), rand_i8((96, 200), 6)
+    out = N.gemm_i8(a.cuda(), b.cuda(), w_layout=N.MIQ_W_KN, out_dtype=torch.int32)
+    np.testing.assert_array_equal(out.cpu().numpy(), OC.linear_w8a8(a.numpy(), b.numpy()))
+    t = N.transpose_i8(b.cuda())
+    np.testing.assert_array_equal(t.cpu().numpy(), b.numpy().T)
+    odd = rand_i8((67, 129), 8)
+    np.testing.assert_array_equal(N.transpose_i8(odd.cuda()).cpu().numpy(), odd.numpy().T)
+
+
+def test_gemm_errors(N):
+    a, w = rand_i8((4, 16), 1).cuda(), rand_i8((8, 32), 2).cuda()
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        N.gemm_i8(a, w)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        N.gemm_i8(a.cpu(), w)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        N.gemm_i8(a, rand_i8((16, 8), 3).cuda().t())
+    with pytest.raises(RuntimeError, match="alpha"):
+        N.gemm_i8(a, rand_i8((8, 16), 3).cuda())
+    with pytest.raises(RuntimeError, match="int8"):
+        N.gemm_i8(a.float(), w)
+    out = N.gemm_i8(torch.empty(0, 16, dtype=torch.int8).cuda(), rand_i8((8, 16), 3).cuda(), out_dtype=torch.int32)
+    assert out.shape == (0, 8)
+
+
+@pytest.mark.parametrize("case", [c for c in FW.cases() if c.startswith("lin")])
+def test_wo_linear_forward_golden(N, case):
+    """Quantize + int8 GEMM + fused weight-only epilogue against the reference's outputs."""
+    w, x, bias = FW.get(case, "w"), FW.get(case, "x"), FW.get(case, "bias")
+    q, s, _ = N.quantize_rows_sym_i8(dev(w))
+    np.testing.assert_array_equal(q.cpu().numpy(), FW.get(case, "q"))
+    y = N.gemm_i8(dev(x), q, bias=None if bias is None else dev(bias), alpha=s, beta=0.0)
+    ref = FW.get(case, "y")
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    np.testing.assert_array_equal(y.cpu().numpy(), O.wo_linear_forward(x, q.cpu().numpy(), s.cpu().numpy(), bias))
+
+
+# ------------------------------------------------------------------------------------ conv
+CONV_SHAPES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (2, 3, 8, 8, 5, 3, 1, 1), (2, 8, 9, 11, 16, 3, 2, 1), (1, 4, 5, 5, 6, 1, 1, 0), (1, 3, 12, 12, 2, 7, 2, 3),
+    (2, 3, 32, 32, 4, 3, 1, 0),      # the reference test's channel counts (conv2d_int8/test.py:17-25), smaller image
+    (3, 16, 14, 14, 32, 3, 1, 1), (2, 64, 14, 14, 64, 3, 1, 1), (2, 64, 15, 15, 128, 3, 2, 1),
+    (2, 64, 14, 14, 128, 1, 2, 0), (4, 128, 7, 7, 256, 3, 1, 1), (1, 5, 6, 7, 3, 2, 1, 0), (1, 1, 4, 4, 1, 3, 1, 2),
+    (2, 3, 30, 30, 64, 7, 2, 3),
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", CONV_SHAPES)
+def test_conv_i32_bit_exact(N, B, C, H, W, Co, k, s, p):
+    x, w = rand_i8((B, C, H, W), B + C * 3 + H), rand_i8((Co, C, k, k), Co + k)
+    ref = OC.conv2d_i8(x.numpy(), w.numpy(), s, p)
+    out = N.conv2d_i8(x.cuda(), w.cuda(), s, p, out_dtype=torch.int32)
+    assert out.shape == ref.shape
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_conv_resnet_layer_vs_torch(N):
+    """A ResNet-18 layer1 shape at a small batch, checked against F.conv2d in float64."""
+    x, w = rand_i8((4, 64, 56, 56), 1), rand_i8((64, 64, 3, 3), 2)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=1, padding=1).to(torch.int32)
+    out = N.conv2d_i8(x.cuda(), w.cuda(), 1, 1, out_dtype=torch.int32)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", [(2, 3, 8, 8, 5, 3, 1, 1), (2, 16, 9, 9, 70, 3, 2, 1), (2, 8, 7, 7, 12, 3, 1, 1)])
+def test_conv_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p):
+    x, w = rand_i8((B, C, H, W), 9), rand_i8((Co, C, k, k), 10)
+    g = torch.Generator().manual_seed(4)
+    alpha, bias = torch.rand(Co, generator=g) * 0.02, torch.randn(Co, generator=g) * 30
+    acc = OC.conv2d_i8(x.numpy(), w.numpy(), s, p)
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), -1.25)
+    out = N.conv2d_i8(x.cuda(), w.cuda(), s, p, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    outb = N.conv2d_i8(x.cuda(), w.cuda(), s, p, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25,
+                       out_dtype=torch.bfloat16)
+    np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
+
+
+@pytest.mark.parametrize("case", [c for c in FW.cases() if c.startswith("conv")])
+def test_wo_conv_forward_golden(N, case):
+    w, x, bias = FW.get(case, "w"), FW.get(case, "x"), FW.get(case, "bias")
+    stride, pad = (int(v) for v in FW.get(case, "stride_pad"))
+    q, s, _ = N.quantize_rows_sym_i8(dev(w))
+    np.testing.assert_array_equal(q.cpu().numpy(), FW.get(case, "q"))
+    y = N.conv2d_i8(dev(x), q, stride, pad, bias=None if bias is None else dev(bias), alpha=s, beta=0.0)
+    ref = FW.get(case, "y")
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+def test_wa_epilogue_golden(N):
+    """Weight+activation epilogue (acc + bias') * scalers + out_zp on the reference's folded params."""
+    for name, conv in (("conv1", True), ("fc2", False)):
+        x, wq = dev(WA.get(name, "x")), dev(WA.get(name, "weight"))
+        bias, scalers = dev(WA.get(name, "bias")), dev(WA.get(name, "scalers"))
+        ozp = float(WA.get(name, "output_zero_point")[0])
+        if conv:
+            y = N.conv2d_i8(x, wq, 1, 1, bias=bias, alpha=scalers, beta=ozp)
+        else:
+            y = N.gemm_i8(x, wq, bias=bias, alpha=scalers, beta=ozp)
+        ref = WA.get(name, "y")
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())

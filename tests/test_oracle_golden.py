@@ -1,0 +1,132 @@
+"""Pin the numpy oracle to the reference: every fixture in tests/golden/ was produced by the
+reference's own Python (oracle/gen_golden.py); the oracle must reproduce each bit for bit
+(int8 / int64 / scales) or to 1e-6 relative (fp32 layer outputs, where the reference ran a
+float GEMM on integer-valued inputs and the oracle an exact integer one)."""
+import numpy as np
+import pytest
+
+from conftest import Golden, kind_of
+from oracle import oracle_np as O
+
+QW = Golden("quantizer_wo.npz")
+QA = Golden("quantizer_wa.npz")
+FW = Golden("wo_forward.npz")
+WA = Golden("wa_chunker.npz")
+C1 = Golden("config1_models.npz")
+
+
+@pytest.mark.parametrize("fix,case", [(QW, c) for c in QW.cases()] + [(QA, c) for c in QA.cases()],
+                         ids=lambda v: v if isinstance(v, str) else "")
+def test_quantizer_matches_reference(fix, case):
+    w = fix.get(case, "w")
+    q, s, zp = O.quantize_channel_sym_int8(w, kind=kind_of(case))
+    assert q.dtype == np.int8 and zp.dtype == np.int64
+    np.testing.assert_array_equal(q, fix.get(case, "q"))
+    np.testing.assert_array_equal(s, fix.get(case, "scales"))
+    np.testing.assert_array_equal(zp, fix.get(case, "zp"))
+    assert s.shape == fix.get(case, "scales").shape
+
+
+def test_edge_rows_hand_checked():
+    """The counter-intuitive rows: signed max (not abs-max), /127.5, eps floor."""
+    q, s, _ = O.quantize_channel_sym_int8(QW.get("edge", "w"))
+    assert q.tolist() == [[-128] * 4, [0] * 4, [127, 0, 2, -2], [127, -128, 64, 32]]
+    eps = np.float32(2.0 ** -23)
+    np.testing.assert_array_equal(
+        s.reshape(-1), np.array([eps, eps, np.float32(1.275) / np.float32(127.5),
+                                 np.float32(2) / np.float32(127.5)], dtype=np.float32))
+
+
+@pytest.mark.parametrize("case", FW.cases())
+def test_wo_forward_matches_reference(case):
+    w, x = FW.get(case, "w"), FW.get(case, "x")
+    bias = FW.get(case, "bias")
+    q, s, _ = O.quantize_channel_sym_int8(w)
+    np.testing.assert_array_equal(q, FW.get(case, "q"))
+    np.testing.assert_array_equal(s.reshape(-1), FW.get(case, "scales"))
+    if case.startswith("lin"):
+        y = O.wo_linear_forward(x, q, s, bias)
+    else:
+        stride, pad = FW.get(case, "stride_pad")
+        y = O.wo_conv2d_forward(x, q, s, bias, int(stride), int(pad))
+    ref = FW.get(case, "y")
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+
+
+def test_wa_epilogue_matches_reference():
+    for name, conv in (("conv1", True), ("fc2", False)):
+        x = WA.get(name, "x")
+        wq = WA.get(name, "weight")
+        bias, scalers = WA.get(name, "bias"), WA.get(name, "scalers")
+        ozp = float(WA.get(name, "output_zero_point")[0])
+        if conv:
+            acc = O.conv2d_int8(x, wq, 1, 1)
+        else:
+            acc = O.linear_w8a8(x, np.ascontiguousarray(wq.T))
+        y = O.epilogue(acc, bias, scalers, ozp)
+        ref = WA.get(name, "y")
+        np.testing.assert_allclose(y, ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+
+
+def test_wa_weight_scales_match_wo_quantizer():
+    """Weight_Activation stores the same per-channel scales the quantizer produced."""
+    for name in ("conv1", "conv2", "fc2"):
+        w = WA.get("fp", f"{name}.weight")
+        q, s, _ = O.quantize_channel_sym_int8(w)
+        np.testing.assert_array_equal(q, WA.get(name, "weight"))
+        np.testing.assert_array_equal(s.reshape(-1), WA.get(name, "weight_qscale"))
+
+
+def test_affine_tensor_params():
+    """calculate_params, per-tensor affine branch, against the values the reference's
+    calibration derived (input_qscale is Qin's scale)."""
+    calib = WA.raw("calib_x")
+    s, zp = O.calculate_params_affine_tensor(calib.min(), calib.max())
+    np.testing.assert_array_equal(s, WA.get("conv1", "input_qscale"))
+    assert zp.dtype == np.int32 and -128 <= int(zp[0]) <= 127
+
+
+def test_config1_small_layers():
+    for model in ("SimpleCNN", "LinearNet", "VGG"):
+        for layer in C1.text(model, "layers").split(","):
+            key = f"{model}/{layer}"
+            if not C1.has(key, "w"):
+                continue
+            q, s, _ = O.quantize_channel_sym_int8(C1.get(key, "w"))
+            np.testing.assert_array_equal(q, C1.get(key, "q"))
+            np.testing.assert_array_equal(s.reshape(-1), C1.get(key, "scales"))
+
+
+def test_linear_w8a8_is_integer_matmul():
+    """The reference's acceptance check (linear_int8/test.py:13-15) on a size where a float
+    matmul is exact."""
+    rng = np.random.default_rng(0)
+    a = rng.integers(-128, 128, (37, 96), dtype=np.int8)
+    b = rng.integers(-128, 128, (96, 53), dtype=np.int8)
+    c = O.linear_w8a8(a, b)
+    assert c.dtype == np.int32
+    np.testing.assert_array_equal(c, a.astype(np.int64) @ b.astype(np.int64))
+
+
+def test_conv2d_int8_matches_torch_conv():
+    """conv2d_int8/test.py:80-97: compare with F.conv2d on integer-valued inputs."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(1)
+    for (B, C, H, W, Co, k, s, p) in [(2, 3, 9, 7, 4, 3, 1, 0), (1, 5, 8, 8, 6, 3, 2, 1),
+                                       (2, 4, 7, 7, 3, 1, 2, 0), (1, 3, 12, 12, 2, 7, 2, 3)]:
+        x = rng.integers(-128, 128, (B, C, H, W), dtype=np.int8)
+        w = rng.integers(-128, 128, (Co, C, k, k), dtype=np.int8)
+        ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), stride=s, padding=p)
+        np.testing.assert_array_equal(O.conv2d_int8(x, w, s, p), ref.numpy().astype(np.int32))
+
+
+def test_shard_rows_partition():
+    for n in (1, 7, 64, 28672):
+        for world in (1, 2, 3, 4, 8):
+            spans = [O.shard_rows(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
