@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: int8 Linear (int8 x int8 -> int32 MFMA GEMM + fused per-channel dequant
+epilogue) at M = N = K = 8192 per GPU, the shape BASELINE.json quotes its target on.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one forward of the layer on int8 activations already resident in HBM, with weights
+produced by the per-channel quantizer from seeded fp32 data.  With N > 1 each rank owns 8192
+output channels of a [8192*N, 8192] layer (weak scaling) and a step also all-gathers the
+[8192, 8192] fp32 output blocks over RCCL, so every rank ends with the full [8192, 8192*N] output.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job int8 TOPS (2*M*N*K integer operations per
+layer).  `roofline` prices the GEMM kernel against the dense int8 MFMA peak with the kernel's own
+duration measured by HIP events on the launch stream; `extra.quantizer` does the same for the
+quantizer kernel against HBM bandwidth.  `cpu_baseline` is the reference's CPU path (restated in
+oracle/oracle_torch.py, pinned to the reference by fixtures) on a bounded sample of the workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 dense peak of MI355X
+PEAK_HBM_GBS = 8000.0     # HBM3E spec
+
+
+def event_times(fn, iters):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    return [s.elapsed_time(e) for s, e in evs]
+
+
+def cpu_baseline(K, N, sample_rows, seed):
+    """Reference CPU path on a bounded sample: quantize a [1024, K] slab of the weight with the
+    reference's row loop, then weight-only forward of `sample_rows` rows against the full weight."""
+    from oracle import oracle_torch as T
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, K, generator=g) * 0.02
+    t0 = time.perf_counter()
+    T.quantize_channel_sym_int8(w[:1024])
+    tq = time.perf_counter() - t0
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int32).to(torch.int8)
+    scale = torch.rand(N, generator=g) * 0.01 + 1e-4
+    zp = torch.zeros(N, dtype=torch.int64)
+    bias = torch.randn(N, generator=g)
+    x = torch.randint(-128, 128, (sample_rows, K), generator=g, dtype=torch.int32).float()
+    T.wo_linear_forward(x[:64], wq, scale, zp, bias)   # warm the thread pool
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T.wo_linear_forward(x, wq, scale, zp, bias)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {
+        "value": round(2.0 * sample_rows * N * K / best / 1e12, 4),
+        "unit": "TOPS",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"weight-only forward of {sample_rows} of the {N} activation rows against the full "
+                  f"[{N},{K}] int8 weight (float GEMM + per-call weight cast, as the reference), best of 3",
+        "quantizer_GBps": round(1024 * K * 5 / tq / 1e9, 3),
+        "quantizer_sample": f"Qop.quantize of a [1024,{K}] fp32 slab (reference's per-row Python loop)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192, help="M = N(per GPU) = K")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from quantization_amd import _native as N_
+    from quantization_amd.sharded import ColumnShardedLinear
+
+    S = args.size
+    M = K = S
+    n_total = S * world
+    g = torch.Generator(device=dev).manual_seed(1234)          # same activations on every rank
+    x = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32, device=dev).to(torch.int8)
+    gw = torch.Generator(device=dev).manual_seed(100 + rank)   # this rank's rows of the weight
+    w_local = torch.randn(S, K, generator=gw, device=dev) * 0.02
+    bias_local = torch.randn(S, generator=gw, device=dev)
+
+    # --- quantizer (timed on its own: extra.quantizer) ------------------------------------
+    nbuf = 6                                                    # 6 x 268 MB rotates past the 256 MiB cache
+    ws = [w_local] + [torch.randn(S, K, generator=gw, device=dev) * 0.02 for _ in range(nbuf - 1)]
+    it = [0]
+
+    def quant_step():
+        N_.quantize_rows_sym_i8(ws[it[0] % nbuf])
+        it[0] += 1
+    for _ in range(nbuf):
+        quant_step()
+    qt = event_times(quant_step, 3 * nbuf)
+    q_ms = sum(qt) / len(qt)
+    q_bytes = S * K * 5 + S * 12
+    wq, scale, _ = N_.quantize_rows_sym_i8(w_local)
+    del ws
+
+    layer = ColumnShardedLinear(wq, scale, bias_local, n_total, out_dtype=torch.float32)
+
+    def step():
+        y = layer.local_forward(x)
+        buf, work = layer.gather_async(y)
+        if work is not None:
+            work.wait()
+        return buf
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # --- GEMM kernel alone, HIP events on the launch stream (roofline) -----------------------
+    out = torch.empty(M, S, dtype=torch.float32, device=dev)
+    gemm = lambda: N_.gemm_i8(x, wq, bias=bias_local, alpha=scale, beta=0.0, out=out)  # noqa: E731
+    for _ in range(3):
+        gemm()
+    kt = event_times(gemm, max(10, args.steps))
+    k_ms = sum(kt) / len(kt)
+    ops_layer = 2.0 * M * S * K
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = ops_layer * world / (ms_per_step * 1e-3) / 1e12
+        achieved = ops_layer / (k_ms * 1e-3) / 1e12
+        line = {
+            "metric": "int8 linear TOPS (M=N=K=8192, fused per-channel dequant epilogue)",
+            "value": round(value, 1),
+            "unit": "TOPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"int8 linear M={M} N={S} per GPU ({n_total} total) K={K}, int8 activations x "
+                            "per-channel-quantized int8 weights -> int32 MFMA accumulate -> fused "
+                            "(acc+bias)*scale fp32 epilogue"
+                            + ("" if world == 1 else f"; column-sharded over {world} GPUs + RCCL all-gather of the fp32 output"),
+                "M": M, "N_per_gpu": S, "K": K, "out_dtype": "float32",
+                "parallelism": "single GPU" if world == 1 else f"column-sharded x{world} + all-gather",
+                "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": round(achieved, 1),
+                "peak": PEAK_INT8_TOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_INT8_TOPS, 4),
+                "traffic": None,
+                "kernel": "gemm_i8_kernel<256,256,2,4>",
+                "kernel_ms": round(k_ms, 4),
+                "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch",
+            },
+            "extra": {
+                "quantizer": {
+                    "workload": f"per-channel symmetric int8 quantize of fp32 [{S},{K}] (5 B/element + 12 B/row)",
+                    "GBps": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
+                    "kernel_ms": round(q_ms, 4),
+                    "roofline": {"bound": "hbm", "achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(q_bytes / (q_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None},
+                },
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

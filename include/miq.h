@@ -92,6 +92,13 @@ int miq_dequantize_rows_i8(const int8_t* q, const float* scale, const int64_t* z
 int miq_dequantize_channels_f32(const float* y, const float* scale, const float* zp, int64_t outer,
                                 int64_t channels, int64_t inner, float* out, void* stream);
 
+/* The layer epilogue applied to a product that was computed in floating point (the
+ * reference's Quantizer.forward on float activations, quant/Weight_Only/Quantizer.py:73-86,
+ * quant/Weight_Activation/Quantizer.py:58-60):
+ *     out[o,c,i] = (y[o,c,i] + bias[c]) * alpha[c] + beta      bias may be NULL. */
+int miq_epilogue_channels_f32(const float* y, const float* bias, const float* alpha, float beta,
+                              int64_t outer, int64_t channels, int64_t inner, float* out, void* stream);
+
 /* int8 Linear: out[m,n] = epilogue( sum_k int32(A[m,k]) * int32(W[n,k]) ).
  *
  * Replaces linear_w8a8(input, weights) (cuda_kernels/linear_int8/linear_w8a8.cpp:11-20,

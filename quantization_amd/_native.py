@@ -33,6 +33,7 @@ SYMBOLS = {
     "miq_quantize_rows_given_i8": (_int, [_p, _int, _i64, _i64, _p, _p, _int, _p, _p]),
     "miq_dequantize_channels_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "miq_dequantize_rows_i8": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "miq_epilogue_channels_f32": (_int, [_p, _p, _p, ctypes.c_float, _i64, _i64, _i64, _p, _p]),
     "miq_gemm_i8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
@@ -239,4 +240,19 @@ def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
     with torch.cuda.device(x.device):
         _check(L.miq_conv2d_i8(_ptr(x), _ptr(w), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
                                float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out
+
+
+def epilogue_channels_f32(y, bias, alpha, beta=0.0):
+    """(y + bias[c]) * alpha[c] + beta along axis 1 of a float tensor y (any float dtype in, fp32 out)."""
+    require_device(y, "y")
+    y = y.to(torch.float32)
+    outer, channels = y.shape[0], y.shape[1]
+    inner = y.numel() // max(outer * channels, 1)
+    bias = _f32_vec(bias, channels, "bias", y.device)
+    alpha = _f32_vec(alpha, channels, "alpha", y.device)
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        _check(lib().miq_epilogue_channels_f32(_ptr(y), _ptr(bias), _ptr(alpha), float(beta), outer, channels,
+                                               inner, _ptr(out), _stream()))
     return out

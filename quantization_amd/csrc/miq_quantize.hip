@@ -445,3 +445,29 @@ extern "C" int miq_dequantize_channels_f32(const float* y, const float* scale, c
         y, scale, zp, outer, channels, inner, out);
     return miq::check_launch("dequantize_channels_kernel");
 }
+
+namespace {
+// out[o,c,i] = (y[o,c,i] + bias[c]) * alpha[c] + beta: the layer epilogue on a float product.
+__global__ __launch_bounds__(kBlock) void epilogue_channels_kernel(const float* __restrict__ y,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ alpha, float beta,
+                                                                   int64_t total, int64_t channels, int64_t inner,
+                                                                   float* __restrict__ out) {
+    for (int64_t idx = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(kBlock) * gridDim.x) {
+        const int64_t c = (idx / inner) % channels;
+        out[idx] = __fadd_rn(__fmul_rn(__fadd_rn(y[idx], bias ? bias[c] : 0.0f), alpha[c]), beta);
+    }
+}
+}  // namespace
+
+extern "C" int miq_epilogue_channels_f32(const float* y, const float* bias, const float* alpha, float beta,
+                                         int64_t outer, int64_t channels, int64_t inner, float* out, void* stream) {
+    MIQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0, MIQ_EINVAL, "miq_epilogue_channels_f32: negative size");
+    const int64_t total = outer * channels * inner;
+    if (total == 0) return MIQ_OK;
+    MIQ_REQUIRE(y && alpha && out, MIQ_EINVAL, "miq_epilogue_channels_f32: null pointer");
+    epilogue_channels_kernel<<<grid_for(miq::ceil_div(total, kBlock)), kBlock, 0, miq::as_stream(stream)>>>(
+        y, bias, alpha, beta, total, channels, inner, out);
+    return miq::check_launch("epilogue_channels_kernel");
+}

@@ -1,0 +1,371 @@
+"""Quantizer layers and Chunker model rewriters with the reference's interface
+(quant/Weight_Only/{Quantizer,Chunker}.py, quant/Weight_Activation/{Quantizer,Chunker}.py).
+
+forward():
+  * int8 activations take the int8 MFMA path: ONE kernel computes the integer product and the
+    layer's whole floating-point tail (bias, per-channel scale, output zero point);
+  * floating-point activations (what the reference's layers are fed) keep the reference's
+    arithmetic: a library float GEMM / convolution on the int8-valued weights, followed by the
+    same tail as one HIP kernel.  The float copy of the weight is cached instead of being
+    re-created on every call (quant/Weight_Only/Quantizer.py:73,79 casts per call).
+Host tensors are staged to the GPU and results returned to the caller's device.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native
+from .qop import QopWeightActivation, QopWeightOnly, _to_gpu
+
+
+def _single(v):
+    """Conv2d hyper-parameters arrive as (a, a) tuples; the int8 kernel takes one integer."""
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise NotImplementedError(f"the int8 convolution needs square stride/padding, got {v}")
+        return int(v[0])
+    return int(v)
+
+
+class _QuantizerBase(nn.Module):
+    def _init_common(self, in_features, out_features, kernel_size, stride, padding, dilation, groups, cnn,
+                     data_metrics):
+        self.in_features = in_features
+        self.out_features = out_features
+        self.cnn = cnn
+        self.data_metrics = data_metrics
+        self.kernel_size = kernel_size if cnn else None
+        self.stride = stride if cnn else None
+        self.padding = padding if cnn else None
+        self.dilation = dilation if cnn else None
+        self.groups = groups if cnn else None
+        self.weight_shape = ((out_features, in_features, *self.kernel_size) if cnn
+                             else (out_features, in_features))
+        # Placeholder until from_float() installs the quantized weight (the reference registers a
+        # random fp16 tensor of this shape, Quantizer.py:34).
+        self.register_buffer("weight", torch.zeros(self.weight_shape, dtype=torch.int8))
+        self._wfloat = None
+        self._wfloat_src = None
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.weight = self.weight.to(*args, **kwargs)
+        if self.bias is not None:
+            self.bias = self.bias.to(*args, **kwargs)
+        self._wfloat = None
+        return self
+
+    # ---- the two products -------------------------------------------------------------
+    def _int8_product(self, x, bias, alpha, beta):
+        w = _to_gpu(self.weight)
+        if self.cnn:
+            if _single(self.dilation) != 1 or self.groups != 1:
+                raise NotImplementedError("the int8 convolution implements dilation 1, groups 1")
+            if isinstance(self.padding, str):
+                raise NotImplementedError("string padding modes are not implemented")
+            return _native.conv2d_i8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha,
+                                     beta=beta)
+        lead = x.shape[:-1]
+        y = _native.gemm_i8(x.reshape(-1, x.shape[-1]).contiguous(), w, bias=bias, alpha=alpha, beta=beta)
+        return y.view(*lead, y.shape[-1])
+
+    def _float_product(self, x, bias, alpha, beta):
+        w = _to_gpu(self.weight)
+        if self._wfloat is None or self._wfloat.dtype != x.dtype or self._wfloat.device != w.device \
+                or self._wfloat_src is not self.weight:
+            self._wfloat, self._wfloat_src = w.to(x.dtype), self.weight
+        if self.cnn:
+            y = F.conv2d(x, self._wfloat, stride=self.stride, padding=self.padding, dilation=self.dilation,
+                         groups=self.groups)
+            return _native.epilogue_channels_f32(y.contiguous(), bias, alpha, beta)
+        y = F.linear(x, self._wfloat)
+        lead = y.shape[:-1]
+        out = _native.epilogue_channels_f32(y.reshape(-1, y.shape[-1]).contiguous(), bias, alpha, beta)
+        return out.view(*lead, out.shape[-1])
+
+    def _run(self, x, bias, alpha, beta):
+        home = x.device
+        xd = _to_gpu(x).contiguous()
+        if xd.dtype == torch.int8:
+            y = self._int8_product(xd, bias, alpha, beta)
+        elif xd.dtype.is_floating_point:
+            y = self._float_product(xd, bias, alpha, beta)
+        else:
+            raise TypeError(f"activations must be int8 or floating point, got {xd.dtype}")
+        return y.to(home)
+
+    def _weight_details(self):
+        dm = self.data_metrics
+        if dm and 'weights' in dm and dm['weights']:
+            sym = "sym" if dm['weights'].get('symentric', True) else "asym"
+            return f"weightq={sym}/{str(dm['weights'].get('dtype', '')).split('.')[-1]}/{dm['weights'].get('affine', '')}"
+        return "weightq=None"
+
+    def _repr(self, details):
+        if self.cnn:
+            return (f"QConv2d({self.in_features}, {self.out_features}, kernel_size={self.kernel_size}, "
+                    f"stride={self.stride}, padding={self.padding}, dilation={self.dilation}, "
+                    f"groups={self.groups}, bias={self.bias is not None} {details})")
+        return f"QLinear({self.in_features}, {self.out_features}, bias={self.bias is not None} {details})"
+
+
+def _layer_kwargs(module):
+    conv = isinstance(module, nn.Conv2d)
+    return dict(
+        in_features=module.in_channels if conv else module.in_features,
+        out_features=module.out_channels if conv else module.out_features,
+        kernel_size=module.kernel_size if conv else None,
+        stride=module.stride if conv else None,
+        padding=module.padding if conv else None,
+        dilation=module.dilation if conv else None,
+        groups=module.groups if conv else None,
+        cnn=conv,
+    )
+
+
+# =====================================================================================
+# Weight-only
+# =====================================================================================
+class WeightOnlyQuantizer(_QuantizerBase):
+    """quant/Weight_Only/Quantizer.py: y = scale[n] * ((x . Wq^T + b[n]) - zero_point[n])."""
+
+    def __init__(self, in_features, out_features, kernel_size=None, stride=None, padding=None, dilation=None,
+                 groups=None, bias=None, quantize_output=False, cnn=False, data_metrics=None, activations=None):
+        super().__init__()
+        self._init_common(in_features, out_features, kernel_size, stride, padding, dilation, groups, cnn,
+                          data_metrics)
+        self.bias = None if bias is None else bias
+        self.input_quant = False
+        self.input_quantizer = QopWeightOnly(dtype=torch.uint8, symmetric=False, affine='tensor', affine_dim=None)
+        self.input_quantizer.max_val = 127
+        self.weight_quant = QopWeightOnly(
+            dtype=data_metrics['weights']['dtype'],
+            symmetric=data_metrics['weights']['symmetric'],
+            affine=data_metrics['weights']['affine'],
+            affine_dim=data_metrics['weights']['affine_dim'],
+        )
+        self.quantize_output = quantize_output
+
+    @torch.no_grad()
+    def forward(self, x):
+        wq = self.weight_quant
+        if not (wq.symmetric and wq.dtype == torch.int8):
+            # zero_point is identically 0 for symmetric int8, the only form quantize() produces
+            raise NotImplementedError("only symmetric int8 weights are implemented")
+        y = self._run(x, self.bias, wq.scales, 0.0)
+        # the reference's dequantize(activation=True) leaves the parameters re-viewed [1,N,...] (Qop.py:175-177)
+        if wq.affine == "channel" and wq.scales.dim() > 1 and wq.scales.shape[1] == 1:
+            wq.zero_point = wq.zero_point.view([1, wq.zero_point.shape[0], *wq.zero_point.shape[2:]])
+            wq.scales = wq.scales.view([1, wq.scales.shape[0], *wq.scales.shape[2:]])
+        return y
+
+    @classmethod
+    def from_float(cls, module, quantize_output=False, activations=None, data_metry=None):
+        new_module = cls(bias=module.bias, quantize_output=quantize_output, data_metrics=data_metry,
+                                         activations=activations, **_layer_kwargs(module))
+        new_module.weight = new_module.weight_quant.quantize(module.weight)
+        return new_module
+
+    def __repr__(self):
+        dm = self.data_metrics
+        if dm and 'outputs' in dm and dm['outputs']:
+            sym = "sym" if dm['outputs'].get('symentric', True) else "asym"
+            out = (f"outputq={sym}/{str(dm['outputs'].get('dtype', '')).split('.')[-1]}/"
+                   f"{dm['outputs'].get('affine', '')}")
+        else:
+            out = "outputq=None"
+        details = self._weight_details()
+        if details != "weightq=None":
+            details = f"{details}, {out}"
+        return self._repr(details)
+
+
+class WeightOnlyChunker:
+    """quant/Weight_Only/Chunker.py: swap every Conv2d / Linear for a quantized layer.
+
+    The reference also runs a ModelAnalyzer pass whose result it never uses (Chunker.py:13);
+    that pass is not reproduced and `mapped_layers` is None.
+    """
+    quantizer_cls = WeightOnlyQuantizer
+
+    def __init__(self, model, calibiration_data):
+        self.model = model
+        self.calibiration_data = calibiration_data
+        self.mapped_layers = None
+        self.interested_layers = []
+        self.chunk()
+
+    def replace_modules(self, module, target_class, look_out_for, module_name_to_exclude=""):
+        for name, child in module.named_children():
+            if isinstance(child, look_out_for) and not any(x == name for x in module_name_to_exclude):
+                if target_class == 'weights':
+                    q_params = {'weights': {'dtype': torch.int8, 'symmetric': True, 'affine': 'channel',
+                                            'affine_dim': 0}}
+                    setattr(module, name, self.quantizer_cls.from_float(module=child, data_metry=q_params,
+                                                                       quantize_output=False))
+            else:
+                self.replace_modules(child, target_class, look_out_for, module_name_to_exclude)
+
+    def weight_quantize(self):
+        self.replace_modules(module=self.model, target_class='weights', look_out_for=(nn.Conv2d, nn.Linear))
+
+    def chunk(self):
+        self.weight_quantize()
+
+
+# =====================================================================================
+# Weight + activation
+# =====================================================================================
+class WeightActivationQuantizer(_QuantizerBase):
+    """quant/Weight_Activation/Quantizer.py: y = (x . Wq^T + bias') * scalers + output_zero_point."""
+
+    def __init__(self, in_features, out_features, kernel_size=None, stride=None, padding=None, dilation=None,
+                 groups=None, bias=None, quantize_output=False, cnn=False, data_metrics=None, activations=None):
+        super().__init__()
+        self._init_common(in_features, out_features, kernel_size, stride, padding, dilation, groups, cnn,
+                          data_metrics)
+        self.bias = bias
+        self.weight_qscale, self.weight_zero_point = None, None
+        self.output_zero_point = None, None
+        self.scalers = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        if self.scalers is None:
+            raise TypeError("scalers are not set: run Chunker.compute_qstats() (the reference fails here too)")
+        n = self.out_features
+        bias = self.bias
+        if bias is not None and bias.numel() == 1 and n != 1:
+            bias = bias.reshape(1).expand(n)  # `torch.tensor(0)` stands for "no bias" (Quantizer.py:81)
+        ozp = self.output_zero_point
+        beta = float(ozp.reshape(-1)[0]) if isinstance(ozp, torch.Tensor) else float(ozp)
+        return self._run(x, bias, self.scalers, beta)
+
+    @classmethod
+    def from_float(cls, module, quantize_output=False, activations=None, data_metry=None):
+        if module.bias is not None:
+            bias = module.bias.view(1, -1, 1, 1) if isinstance(module, nn.Conv2d) else module.bias.view(1, -1)
+        else:
+            bias = torch.tensor(0)
+        new_module = cls(bias=bias, quantize_output=quantize_output, data_metrics=data_metry,
+                                               activations=activations, **_layer_kwargs(module))
+        weight_quant = QopWeightActivation(
+            dtype=data_metry['weights']['dtype'],
+            symmetric=data_metry['weights']['symmetric'],
+            affine=data_metry['weights']['affine'],
+            affine_dim=data_metry['weights']['affine_dim'],
+        )
+        new_module.weight = weight_quant.quantize(module.weight)
+        new_module.weight_qscale, new_module.weight_zero_point = weight_quant.scales, weight_quant.zero_point
+        return new_module
+
+    def __repr__(self):
+        return self._repr(self._weight_details())
+
+
+class QuantizedMaxPool2d(nn.MaxPool2d):
+    """quant/Weight_Activation/Quantizer.py:122-125."""
+
+    def forward(self, x):
+        return super().forward(x.float()).to(torch.int8)
+
+
+class QuantizedAvgPool2d(nn.AvgPool2d):
+    """quant/Weight_Activation/Quantizer.py:127-130."""
+
+    def forward(self, x):
+        return super().forward(x.float()).to(torch.int8)
+
+
+class WeightActivationChunker:
+    """quant/Weight_Activation/Chunker.py: observe activations, quantize weights, fold the
+    statistics into each layer's `bias` / `scalers` / `output_zero_point`.
+
+    The calibration arithmetic is reproduced as the reference computes it, including what it
+    names oddly: `input_zero_point` and `output_zero_point` both hold the OUTPUT scale, and the
+    running minimum of the outputs is fed with output.max() (Chunker.py:47,95-96).
+    """
+    quantizer_cls = WeightActivationQuantizer
+
+    def __init__(self, model, calibiration_data):
+        self.model = model
+        self.calibiration_data = calibiration_data
+        self.mapped_layers = None
+        self.interested_layers = []
+        self.hooks = {}
+        self.attached_hooks = []
+        self.chunk()
+
+    def _stat_observer(self, module, input, output, module_name):
+        x = input[0]
+        h = self.hooks.setdefault(module_name, {'input_stats': [float('inf'), float('-inf')],
+                                                'output_stats': [float('inf'), float('-inf')]})
+        h['type'] = type(module)
+        h['input_stats'] = [min(h['input_stats'][0], x.min()), max(h['input_stats'][1], x.max())]
+        h['output_stats'] = [min(h['output_stats'][0], output.max()), max(h['output_stats'][1], output.max())]
+
+    def _compute_qstats(self, name, child):
+        qin = QopWeightActivation(dtype=torch.int8, symmetric=False, affine='tensor', affine_dim=None)
+        qout = QopWeightActivation(dtype=torch.int8, symmetric=False, affine='tensor', affine_dim=None)
+        qin.min_val, qin.max_val = self.hooks[name]['input_stats']
+        qout.min_val, qout.max_val = self.hooks[name]['output_stats']
+        child.input_qscale = qin.calculate_params()[0].item()
+        child.input_zero_point = qout.calculate_params()[0].item()
+        child.output_qscale = qout.calculate_params()[0].item()
+        child.output_zero_point = qout.calculate_params()[0]
+        shape = (1, -1, 1, 1) if child.weight.dim() == 4 else (1, -1)
+        dims = (1, 2, 3) if child.weight.dim() == 4 else 1
+        qweight = child.weight.sum(dims)
+        child.bias = (child.bias.squeeze() - qweight.to(torch.int32) * child.input_zero_point).squeeze().view(shape)
+        child.scalers = ((child.input_qscale * child.weight_qscale) / child.output_qscale).squeeze().view(shape)
+
+    def replace_modules(self, module, target_class, look_out_for, module_name_to_exclude=""):
+        for name, child in module.named_children():
+            if isinstance(child, look_out_for) and not any(x == name for x in module_name_to_exclude):
+                if target_class == 'weights':
+                    q_params = {'weights': {'dtype': torch.int8, 'symmetric': True, 'affine': 'channel',
+                                            'affine_dim': 0}}
+                    setattr(module, name, self.quantizer_cls.from_float(module=child, data_metry=q_params,
+                                                                       quantize_output=False))
+                elif target_class == 'attach_observers':
+                    self.attached_hooks.append(child.register_forward_hook(
+                        functools.partial(self._stat_observer, module_name=name)))
+                elif target_class == 'misc_layers':
+                    if isinstance(child, nn.MaxPool2d):
+                        setattr(module, name, QuantizedMaxPool2d(kernel_size=child.kernel_size, stride=child.stride,
+                                                                 padding=child.padding))
+                    elif isinstance(child, nn.AvgPool2d):
+                        setattr(module, name, QuantizedAvgPool2d(kernel_size=child.kernel_size, stride=child.stride,
+                                                                 padding=child.padding))
+                elif target_class == 'compute_qstats':
+                    self._compute_qstats(name, child)
+            else:
+                self.replace_modules(child, target_class, look_out_for, module_name_to_exclude)
+
+    def weight_quantize(self):
+        self.replace_modules(module=self.model, target_class='weights', look_out_for=(nn.Conv2d, nn.Linear))
+
+    def calibirate_model(self):
+        device = next(self.model.parameters()).device
+        with torch.no_grad():
+            for input_data, _ in self.calibiration_data:
+                self.model(input_data.to(device))
+
+    def attach_observers_observe(self):
+        self.replace_modules(module=self.model, target_class='attach_observers', look_out_for=(nn.Conv2d, nn.Linear))
+        self.calibirate_model()
+        for hook in self.attached_hooks:
+            hook.remove()
+
+    def compute_qstats(self):
+        self.replace_modules(module=self.model, target_class='compute_qstats', look_out_for=self.quantizer_cls)
+
+    def misc_layers(self):
+        self.replace_modules(module=self.model, target_class='misc_layers', look_out_for=(nn.MaxPool2d, nn.AvgPool2d))
+
+    def chunk(self):
+        self.attach_observers_observe()
+        self.weight_quantize()
+        self.compute_qstats()

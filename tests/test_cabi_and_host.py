@@ -1,0 +1,143 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/miq.h declares, argument
+validation works without a device, and the host-side logic (parameter formulas, sharding,
+layer bookkeeping) matches the oracle.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, Golden
+from oracle import oracle_np as O
+
+WA = Golden("wa_chunker.npz")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "miq.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(miq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from quantization_amd import _native
+    lib = _native.lib()
+    declared = header_functions()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/miq.h but not exported"
+    assert sorted(_native.SYMBOLS) == declared, "ctypes table and header disagree"
+    assert lib.miq_version() == 100
+
+
+def test_argument_validation_needs_no_device():
+    from quantization_amd import _native
+    lib = _native.lib()
+    null = ctypes.c_void_p(0)
+    assert lib.miq_quantize_rows_sym_i8(null, 0, -1, 4, null, null, null, null, null) == -1
+    assert b"negative" in lib.miq_last_error()
+    assert lib.miq_quantize_rows_sym_i8(null, 0, 2, 4, null, null, null, null, null) == -1
+    assert b"null" in lib.miq_last_error()
+    assert lib.miq_quantize_rows_sym_i8(ctypes.c_void_p(64), 9, 2, 4, ctypes.c_void_p(64), ctypes.c_void_p(64),
+                                        ctypes.c_void_p(64), null, null) == -1
+    assert b"w_dtype" in lib.miq_last_error()
+    assert lib.miq_gemm_i8(null, null, 7, 1, 1, 16, null, null, 0.0, null, 0, null, 0, null) == -1
+    assert lib.miq_gemm_i8(ctypes.c_void_p(64), ctypes.c_void_p(64), 0, 4, 4, 16, null, null, 0.0,
+                           ctypes.c_void_p(64), 0, null, 0, null) == -1
+    assert b"alpha" in lib.miq_last_error()
+    # [K,N] weights without workspace
+    assert lib.miq_gemm_i8(ctypes.c_void_p(64), ctypes.c_void_p(64), 1, 4, 4, 16, null, null, 0.0,
+                           ctypes.c_void_p(64), 3, null, 0, null) == -3
+    assert lib.miq_gemm_i8(ctypes.c_void_p(64), ctypes.c_void_p(64), 0, 1 << 20, 4, 1 << 20, null, null, 0.0,
+                           ctypes.c_void_p(64), 3, null, 0, null) == -5
+    assert lib.miq_gemm_i8_workspace(1, 8, 100, 64) == 6400 and lib.miq_gemm_i8_workspace(0, 8, 100, 64) == 0
+    assert lib.miq_conv2d_i8(ctypes.c_void_p(64), ctypes.c_void_p(64), 1, 3, 2, 2, 4, 3, 3, 1, 0, null, null, 0.0,
+                             ctypes.c_void_p(64), 3, null, 0, null) == -1   # kernel larger than the input
+    # 256 x (58*58*64) padded activations + 64 x (3*192) packed weights, each rounded to 256 B
+    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 64, 3, 3, 1, 1) == 256 * 58 * 58 * 64 + 64 * 576
+    # zero-sized problems succeed without touching a device
+    assert lib.miq_gemm_i8(null, null, 0, 0, 8, 16, null, null, 0.0, null, 3, null, 0, null) == 0
+    assert lib.miq_quantize_rows_sym_i8(null, 0, 0, 16, null, null, null, null, null) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product raises instead of computing anything on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from quantization_amd.quant.Weight_Only import Qop
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        Qop(dtype=torch.int8, symmetric=True, affine="channel", affine_dim=0).quantize(torch.randn(4, 8))
+    from quantization_amd import linear_w8a8
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        linear_w8a8.linear_w8a8(torch.zeros(2, 16, dtype=torch.int8), torch.zeros(16, 2, dtype=torch.int8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "quantization_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text, f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("pkg", ["Weight_Only", "Weight_Activation"])
+def test_calculate_params_matches_oracle(pkg):
+    import importlib
+    Qop = importlib.import_module(f"quantization_amd.quant.{pkg}").Qop
+    rng = np.random.default_rng(3)
+    mx = rng.standard_normal(50).astype(np.float32)
+    mx[:4] = [0.0, -3.0, 1e-9, 2.0]
+    q = Qop(dtype=torch.int8, symmetric=True, affine="channel", affine_dim=0)
+    q.max_val = torch.from_numpy(mx)
+    q.min_val = torch.zeros(50)
+    s, zp = q.calculate_params()
+    rs, rzp = O.calculate_params_symmetric(mx)
+    np.testing.assert_array_equal(s.numpy(), rs)
+    assert zp.dtype == torch.int64 and not zp.any()
+    qt = Qop(dtype=torch.int8, symmetric=False, affine="tensor", affine_dim=None)
+    calib = WA.raw("calib_x")
+    qt.min_val, qt.max_val = torch.tensor(calib.min()), torch.tensor(calib.max())
+    s, zp = qt.calculate_params()
+    np.testing.assert_array_equal(s.numpy(), WA.get("conv1", "input_qscale"))
+    assert s.shape == (1,) and zp.shape == (1,) and zp.dtype == torch.int32
+    qu = Qop(dtype=torch.uint8, symmetric=True, affine="tensor")
+    qu.min_val, qu.max_val = torch.tensor(-1.0), torch.tensor(2.0)
+    s, zp = qu.calculate_params()
+    assert int(zp[0]) == 127 and abs(float(s[0]) - 2.0 / 127.5) < 1e-9
+
+
+def test_qop_constructor_signatures():
+    from quantization_amd.quant.Weight_Activation import Qop as QA
+    from quantization_amd.quant.Weight_Only import Qop as QW
+    a = QW(torch.int8, None, 'channel', 0, -1, True)
+    assert (a.q_min, a.q_max, a.affine, a.affine_dim, a.symmetric) == (-128, 127, 'channel', 0, True)
+    assert float(a.eps) == 2.0 ** -23 and a.scales is None and a.zero_point is None and a.max_val is None
+    b = QA(torch.int8, None, None, 'channel', 0, -1, True)   # extra `bits` argument in second place
+    assert (b.q_min, b.q_max, b.affine, b.symmetric) == (-128, 127, 'channel', True)
+    assert not hasattr(QA(), "dtype")                        # dtype is optional there (Qop.py:8-14)
+
+
+def test_quantizer_construction_and_repr():
+    from quantization_amd.quant.Weight_Only import Quantizer
+    dm = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+    lin = Quantizer(6, 4, bias=None, data_metrics=dm)
+    assert lin.weight.shape == (4, 6) and "weight" in dict(lin.named_buffers())
+    assert repr(lin) == "QLinear(6, 4, bias=False weightq=sym/int8/channel, outputq=None)"
+    conv = Quantizer(3, 5, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1,
+                     bias=torch.zeros(5), cnn=True, data_metrics=dm)
+    assert conv.weight.shape == (5, 3, 3, 3)
+    assert repr(conv) == ("QConv2d(3, 5, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), dilation=(1, 1), "
+                          "groups=1, bias=True weightq=sym/int8/channel, outputq=None)")
+    from quantization_amd.quant.Weight_Activation import Quantizer as QA
+    assert repr(QA(6, 4, bias=None, data_metrics=dm)) == "QLinear(6, 4, bias=False weightq=sym/int8/channel)"
+
+
+def test_shard_rows_matches_oracle():
+    from quantization_amd.sharded import shard_rows
+    for n in (1, 7, 64, 28672, 8192):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                assert shard_rows(n, world, r) == O.shard_rows(n, world, r)

@@ -130,3 +130,25 @@ def test_shard_rows_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_torch_baseline_port_matches_reference():
+    """oracle/oracle_torch.py (the CPU baseline bench.py times) against the same fixtures."""
+    import torch
+    from oracle import oracle_torch as T
+    for case in ("edge", "f32_10x512", "f32_257x1000", "conv_16x8x3x3", "ties"):
+        q, s, zp = T.quantize_channel_sym_int8(torch.from_numpy(QW.get(case, "w")))
+        np.testing.assert_array_equal(q.numpy(), QW.get(case, "q"))
+        np.testing.assert_array_equal(s.numpy(), QW.get(case, "scales"))
+        np.testing.assert_array_equal(zp.numpy(), QW.get(case, "zp"))
+    for case in FW.cases():
+        q, s, zp = T.quantize_channel_sym_int8(torch.from_numpy(FW.get(case, "w")))
+        x = torch.from_numpy(FW.get(case, "x")).float()
+        b = FW.get(case, "bias")
+        b = None if b is None else torch.from_numpy(b)
+        if case.startswith("lin"):
+            y = T.wo_linear_forward(x, q, s, zp, b)
+        else:
+            stride, pad = (int(v) for v in FW.get(case, "stride_pad"))
+            y = T.wo_conv2d_forward(x, q, s, zp, b, stride, pad)
+        np.testing.assert_array_equal(y.numpy(), FW.get(case, "y"))

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmarks for the individual kernels (not the driver's bench.py).
+
+    python tools/kbench.py [quant] [gemm] [conv] [small]
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quantization_amd import _native as N  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def rand_i8(shape):
+    return torch.randint(-128, 128, shape, dtype=torch.int32, device="cuda").to(torch.int8)
+
+
+def bench_quant():
+    for rows, cols, dt in [(4096, 4096, torch.float32), (14336, 4096, torch.float32), (4096, 14336, torch.float32),
+                           (28672, 8192, torch.float32), (8192, 28672, torch.float32),
+                           (14336, 4096, torch.bfloat16), (28672, 8192, torch.float16)]:
+        nbuf = max(2, int(2e9 // (rows * cols * 4)))
+        ws = [torch.randn(rows, cols, device="cuda", dtype=torch.float32).to(dt) * 0.02 for _ in range(nbuf)]
+        i = [0]
+
+        def fn():
+            N.quantize_rows_sym_i8(ws[i[0] % nbuf])
+            i[0] += 1
+        med, mn = timeit(fn, iters=3 * nbuf)
+        es = ws[0].element_size()
+        byts = rows * cols * (es + 1) + rows * 12
+        print(f"quant {rows}x{cols} {str(dt)[6:]}: med {med*1e3:.1f} us  {byts/med/1e9:.0f} GB/s (min {byts/mn/1e9:.0f})", flush=True)
+        del ws
+
+
+def bench_gemm(shapes=None):
+    shapes = shapes or [(4096, 4096, 4096), (8192, 8192, 8192), (256, 14336, 4096), (256, 4096, 14336),
+                        (8192, 28672, 8192), (2048, 8192, 8192)]
+    for M, Nn, K in shapes:
+        a, w = rand_i8((M, K)), rand_i8((Nn, K))
+        alpha = torch.rand(Nn, device="cuda") * 0.01
+        bias = torch.randn(Nn, device="cuda")
+        for od in (torch.float32, torch.bfloat16, torch.int32):
+            out = torch.empty(M, Nn, dtype=od, device="cuda")
+            fn = lambda: N.gemm_i8(a, w, bias=bias, alpha=alpha, beta=0.0, out_dtype=od, out=out)  # noqa: E731
+            med, mn = timeit(fn)
+            ops = 2.0 * M * Nn * K
+            print(f"gemm M={M} N={Nn} K={K} out={str(od)[6:]}: med {med*1e3:.1f} us  {ops/med/1e9:.0f} TOPS (best {ops/mn/1e9:.0f})", flush=True)
+
+
+def bench_small():
+    for M in (1, 8, 16, 32, 64, 128, 256):
+        for Nn, K in ((14336, 4096), (4096, 14336)):
+            a, w = rand_i8((M, K)), rand_i8((Nn, K))
+            alpha = torch.rand(Nn, device="cuda") * 0.01
+            out = torch.empty(M, Nn, dtype=torch.float32, device="cuda")
+            fn = lambda: N.gemm_i8(a, w, alpha=alpha, out=out)  # noqa: E731
+            med, mn = timeit(fn)
+            print(f"gemm M={M} N={Nn} K={K}: med {med*1e3:.1f} us  {2.0*M*Nn*K/med/1e9:.1f} TOPS  weight {Nn*K/med/1e6:.0f} GB/s", flush=True)
+
+
+def bench_conv():
+    cfgs = [(256, 3, 224, 64, 7, 2, 3), (256, 64, 56, 64, 3, 1, 1), (256, 64, 56, 128, 3, 2, 1), (256, 128, 28, 128, 3, 1, 1),
+            (256, 64, 56, 128, 1, 2, 0), (256, 128, 28, 256, 3, 2, 1), (256, 256, 14, 256, 3, 1, 1),
+            (256, 256, 14, 512, 3, 2, 1), (256, 512, 7, 512, 3, 1, 1)]
+    for B, C, H, Co, k, s, p in cfgs:
+        x, w = rand_i8((B, C, H, H)), rand_i8((Co, C, k, k))
+        alpha = torch.rand(Co, device="cuda") * 0.01
+        Ho = (H + 2 * p - k) // s + 1
+        for od in (torch.int32, torch.bfloat16):
+            out = torch.empty(B, Co, Ho, Ho, dtype=od, device="cuda")
+            fn = lambda: N.conv2d_i8(x, w, s, p, alpha=alpha, out_dtype=od, out=out)  # noqa: E731
+            med, mn = timeit(fn, iters=10, warmup=3)
+            ops = 2.0 * B * Co * Ho * Ho * C * k * k
+            print(f"conv B={B} {C}->{Co} {H}x{H} k{k}s{s}p{p} out={str(od)[6:]}: med {med*1e3:.1f} us  {ops/med/1e9:.0f} TOPS", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["quant", "gemm", "conv", "small"]
+    t0 = time.time()
+    if "quant" in which:
+        bench_quant()
+    if "gemm" in which:
+        bench_gemm()
+    if "small" in which:
+        bench_small()
+    if "conv" in which:
+        bench_conv()
+    print(f"done in {time.time()-t0:.1f}s")
