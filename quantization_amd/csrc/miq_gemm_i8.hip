@@ -173,6 +173,282 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 256 x 256 tile, software-pipelined: the kernel large GEMMs run on.
+//
+// 8 waves as 2 (m) x 4 (n); a wave owns 128 x 64 outputs as four 64 x 32 quadrants.  Each
+// 128-byte K-tile is kept in LDS as four 16 KiB half-tiles: A0/A1 = activation rows 0-127 /
+// 128-255 of the block, W0/W1 likewise for the weight rows.  Quadrant (qm, qn) of wave
+// (wm, wn) covers rows qm*128 + wm*64 .. +64 and columns qn*128 + wn*32 .. +32, so quadrant q
+// reads only half-tile q.  Two K-tile buffers (128 KiB).
+//
+// A K-tile is four phases of 16 MFMAs (one quadrant each).  A phase is a LOAD segment (LDS
+// fragment reads + one half-tile of LDS-DMA for a later K-tile + a counted vmcnt), a raw barrier,
+// an MFMA segment, a raw barrier:
+//   P1: read W0,A0 of tile t | DMA W1(t+1) | vmcnt(8) | barrier | MFMA quadrant (0,0) | barrier
+//   P2: read W1              | DMA A1(t+1) | vmcnt(8) | barrier | MFMA (0,1)          | barrier
+//   P3: read A1              | DMA A0(t+2) | vmcnt(8) | barrier | MFMA (1,1)          | barrier
+//   P4:                      | DMA W0(t+2) | vmcnt(8) | barrier | MFMA (1,0)          | barrier
+// Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so while one group
+// is in an MFMA segment the other is in a LOAD segment and the matrix pipe is not left waiting.
+// Every wave issues exactly two DMA instructions per phase (tiles past K are fetched as
+// out-of-range: zero-filled, no memory traffic), so vmcnt(8) after a phase's issue means "the
+// half-tile issued four phases ago has landed": each half-tile has four phases of flight, four
+// half-tiles (64 KiB) are in flight per CU, and the wait that retires a half-tile sits one
+// barrier before its first read.  A half-tile is re-staged at least two phases after its last
+// read, whose data the MFMAs of that phase have consumed before the barrier that ends it.
+// ---------------------------------------------------------------------------------------
+#define MIQ_BARRIER()                       \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();       \
+        asm volatile("" ::: "memory");      \
+    } while (0)
+
+template <int OUT, int VARIANT, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
+    constexpr int kHalf = 128 * kTileK;   // one half-tile: 128 rows x 128 B
+    constexpr int kBuf = 4 * kHalf;       // A0 A1 W0 W1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, static_cast<uint32_t>(g.M) * g.K);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+
+    // Staging: a wave-instruction moves 8 rows x 128 B; a wave issues two per half-tile (row
+    // groups `wave` and `wave + 8`).  The chunk a lane fetches is fixed by the swizzle.
+    const int srow = wave * 8 + (lane >> 3);                    // row inside the half-tile, first piece
+    const int cbyte = ((lane & 7) ^ ((srow >> 1) & 7)) * kChunk;
+    uint32_t abase[2][2], wbase[2][2];                          // [half][piece] byte offset at k = 0
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ra_ = m0 + h * 128 + srow + i * 64, rw_ = n0 + h * 128 + srow + i * 64;
+            abase[h][i] = ra_ < g.M ? static_cast<uint32_t>(ra_) * g.K + cbyte : kOob;
+            wbase[h][i] = rw_ < g.N ? static_cast<uint32_t>(rw_) * g.K + cbyte : kOob;
+        }
+    auto stage_half = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, const uint32_t (&base)[2], int kt) {
+        int k = kt * kTileK;
+        bool k_ok = k + cbyte < g.K;
+        if ((ABL & 1) && kt > 1) return;   // timing-only builds: no DMA in the main loop,
+        if ((ABL & 4) && kt > 1) k_ok = false;   // DMA issued but out of range (no memory traffic),
+        if ((ABL & 8) && kt > 1) k = (kt & 1) * kTileK;   // or always the same two K-tiles (cache-hot)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t off = (k_ok && base[i] != kOob) ? base[i] + k : kOob;
+            dma16(rs, dst + (wave + 8 * i) * (8 * kTileK), off);
+        }
+    };
+
+    v4i acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = v4i{0, 0, 0, 0};
+
+    const int nt = (g.K + kTileK - 1) / kTileK;
+    const int lo[2] = {frag_lane_offset(lane, 0), frag_lane_offset(lane, 1)};
+    const int a_frag = wm * 64 * kTileK;   // this wave's rows inside an A half-tile
+    const int w_frag = wn * 32 * kTileK;   // and inside a W half-tile
+
+    // Prologue: all of tile 0 plus A0/W0 of tile 1; wait for tile 0 only.
+    stage_half(ra, smem + 0 * kHalf, abase[0], 0);
+    stage_half(rw, smem + 2 * kHalf, wbase[0], 0);
+    stage_half(rw, smem + 3 * kHalf, wbase[1], 0);
+    stage_half(ra, smem + 1 * kHalf, abase[1], 0);
+    stage_half(ra, smem + kBuf + 0 * kHalf, abase[0], 1);
+    stage_half(rw, smem + kBuf + 2 * kHalf, wbase[0], 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0(0), W0(0); in VARIANT 1 also the rest of tile 0
+    if constexpr (VARIANT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    MIQ_BARRIER();
+    // Waves 4-7 (the second wave on each SIMD) run one barrier behind waves 0-3: while one group
+    // issues MFMAs the other does its LDS reads and DMA, so the matrix pipe never waits for loads.
+    if (wm == 1) MIQ_BARRIER();
+
+    v4i af[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [k-step][fragment]
+    auto read_w = [&](v4i (&wf)[2][2], const char* half) {
+        if (ABL & 2) {   // timing-only build: no LDS reads, operands made opaque
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(wf[ks][j]));
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[ks][j] = lds_read16(half + w_frag + j * 16 * kTileK + lo[ks]);
+    };
+    auto read_a = [&](const char* half) {
+        if (ABL & 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[ks][i]));
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = lds_read16(half + a_frag + i * 16 * kTileK + lo[ks]);
+    };
+    auto mma = [&](v4i (&c)[4][2], const v4i (&wf)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][j], af[ks][i], c[i][j], 0, 0, 0);
+    };
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * kBuf;
+        char* nxt = smem + ((t + 1) & 1) * kBuf;
+        if constexpr (VARIANT == 0) {
+            // four phases of 16 MFMAs, two barriers each
+            read_w(wf0, cur + 2 * kHalf);
+            read_a(cur + 0 * kHalf);
+            stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W1(t) has landed
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][0], wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+
+            read_w(wf1, cur + 3 * kHalf);
+            stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A1(t)
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][1], wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+
+            read_a(cur + 1 * kHalf);
+            stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0(t+1)
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][1], wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+
+            stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W0(t+1)
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][0], wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+        } else {
+            // two phases of 32 MFMAs, two barriers each; LDS reads are drained before the barrier that
+            // ends a load segment, so a half-tile may be restaged one phase after its last read
+            read_w(wf0, cur + 2 * kHalf);
+            read_a(cur + 0 * kHalf);
+            read_w(wf1, cur + 3 * kHalf);
+            stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
+            stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][0], wf0);
+            mma(acc[0][1], wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+
+            read_a(cur + 1 * kHalf);
+            stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
+            stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            MIQ_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][1], wf1);
+            mma(acc[1][0], wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_BARRIER();
+        }
+    }
+    if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
+
+    // Epilogue.  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
+    const bool vec_ok = (g.N & 3) == 0;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
+            float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (OUT != kOutI32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) {
+                        al[e] = g.alpha[n + e];
+                        if (g.bias) bi[e] = g.bias[n + e];
+                    }
+            }
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
+                    if (m >= g.M || n >= g.N) continue;
+                    const v4i a = acc[qm][qn][i][j];
+                    const size_t idx = static_cast<size_t>(m) * g.N + n;
+                    if constexpr (OUT == kOutI32) {
+                        int* o = static_cast<int*>(g.out) + idx;
+                        if (vec_ok && n + 3 < g.N) {
+                            *reinterpret_cast<v4i*>(o) = a;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < g.N) o[e] = a[e];
+                        }
+                    } else {
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
+                        if constexpr (OUT == kOutF32) {
+                            float* o = static_cast<float*>(g.out) + idx;
+                            if (vec_ok && n + 3 < g.N) {
+                                *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < g.N) o[e] = y[e];
+                            }
+                        } else {
+                            uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
+                            if (vec_ok && n + 3 < g.N) {
+                                uint2 p;
+                                p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
+                                p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
+                                *reinterpret_cast<uint2*>(o) = p;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
+                            }
+                        }
+                    }
+                }
+        }
+}
+
 // Any K and any alignment: one thread per output element.  Only shapes the MFMA path cannot
 // take (K not a multiple of 16, or misaligned pointers) come here; they are tiny layers.
 template <int OUT>
@@ -238,7 +514,27 @@ int launch(GemmArgs g, bool mfma_ok, hipStream_t st) {
     // Tile choice: the 256x256 tile (8 waves, 128 KiB LDS) once both dimensions can fill the
     // chip with it; smaller tiles keep more workgroups in flight for thin problems.
     const int64_t big_tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
-    if (g.M > 128 && big_tiles >= 192) return launch_tile<256, 256, 2, 4, OUT>(g, st);
+    if (g.M > 128 && big_tiles >= 192) {
+        const char* simple = getenv("MIQ_GEMM_SIMPLE");   // developer A/B switch
+        if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
+        g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
+        g.tiles_n = static_cast<int>(ceil_div(g.N, 256));
+        constexpr int kLds = 2 * 4 * 128 * kTileK;
+        const char* var = getenv("MIQ_GEMM_VARIANT");     // developer A/B switch
+        auto kern = (var && var[0] == '1') ? gemm_i8_256_kernel<OUT, 1> : gemm_i8_256_kernel<OUT, 0>;
+        const char* abl = getenv("MIQ_GEMM_ABL");
+        if (abl && OUT == kOutF32) {
+            if (abl[0] == '1') kern = gemm_i8_256_kernel<OUT, 0, 1>;
+            if (abl[0] == '2') kern = gemm_i8_256_kernel<OUT, 0, 2>;
+            if (abl[0] == '3') kern = gemm_i8_256_kernel<OUT, 0, 3>;
+            if (abl[0] == '4') kern = gemm_i8_256_kernel<OUT, 0, 4 + 2>;
+            if (abl[0] == '5') kern = gemm_i8_256_kernel<OUT, 0, 8 + 2>;
+            if (abl[0] == '6') kern = gemm_i8_256_kernel<OUT, 0, 8>;
+        }
+        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+        kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
+        return check_launch("gemm_i8_256_kernel");
+    }
     if (g.M > 64) return launch_tile<128, 128, 2, 2, OUT>(g, st);
     if (g.M > 32) return launch_tile<64, 64, 2, 2, OUT>(g, st);
     if (g.M > 16) return launch_tile<32, 64, 1, 4, OUT>(g, st);

@@ -12,9 +12,15 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "miq_common.h"
 
 namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kEps = 1.1920928955078125e-07f;  // 2^-23 = torch.finfo(float32).eps
 constexpr int kBlock = 256;
@@ -115,15 +121,16 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Row held in registers.  TPR threads cooperate on one row (64 = one wave, 256 = the whole
 // workgroup); each keeps NV 16-byte vectors.  Rows are walked with a grid stride.
-template <int DT, int NV, int TPR>
-__global__ __launch_bounds__(kBlock) void quantize_rows_reg_kernel(const uint4* __restrict__ w,
+template <int DT, int NV, int TPR, bool NT = false, int BLOCK = (TPR > kBlock ? TPR : kBlock)>
+__global__ __launch_bounds__(BLOCK) void quantize_rows_reg_kernel(const uint4* __restrict__ w,
                                                                    int64_t rows, int nvec, int8_t* __restrict__ q,
                                                                    float* __restrict__ scale,
                                                                    int64_t* __restrict__ zp,
                                                                    float* __restrict__ row_max) {
     using V = Vec<DT>;
-    constexpr int kRowsPerBlock = kBlock / TPR;
-    __shared__ float red[2][kBlock / 64];
+    constexpr int kRowsPerBlock = BLOCK / TPR;
+    constexpr int kWavesPerRow = TPR / 64;
+    __shared__ float red[2][BLOCK / 64];
     const int t = threadIdx.x % TPR;
     const int sub = threadIdx.x / TPR;
     int phase = 0;
@@ -138,7 +145,12 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_reg_kernel(const uint4* 
         for (int j = 0; j < NV; ++j) {
             const int idx = t + j * TPR;
             if (live && idx < nvec) {
-                v[j] = src[idx];
+                if constexpr (NT) {
+                    const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&src[idx]));
+                    v[j] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                } else {
+                    v[j] = src[idx];
+                }
                 float f[V::kElems];
                 V::unpack(v[j], f);
 #pragma unroll
@@ -149,7 +161,9 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_reg_kernel(const uint4* 
         if constexpr (TPR > 64) {
             if ((threadIdx.x & 63) == 0) red[phase][threadIdx.x >> 6] = m;
             __syncthreads();
-            m = fmaxf(fmaxf(red[phase][0], red[phase][1]), fmaxf(red[phase][2], red[phase][3]));
+            m = red[phase][0];
+#pragma unroll
+            for (int k = 1; k < kWavesPerRow; ++k) m = fmaxf(m, red[phase][k]);
             phase ^= 1;  // the other slot is free again after the next row's barrier
         }
         const float s = scale_from_max<DT>(m);
@@ -168,10 +182,20 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_reg_kernel(const uint4* 
                 int r[V::kElems];
 #pragma unroll
                 for (int e = 0; e < V::kElems; ++e) r[e] = quantize_one<DT>(f[e], s);
+                typename V::Store pk;
                 if constexpr (V::kElems == 4) {
-                    dst[idx] = pack4(r[0], r[1], r[2], r[3]);
+                    pk = pack4(r[0], r[1], r[2], r[3]);
                 } else {
-                    dst[idx] = make_uint2(pack4(r[0], r[1], r[2], r[3]), pack4(r[4], r[5], r[6], r[7]));
+                    pk = make_uint2(pack4(r[0], r[1], r[2], r[3]), pack4(r[4], r[5], r[6], r[7]));
+                }
+                if constexpr (NT) {
+                    if constexpr (V::kElems == 4) {
+                        __builtin_nontemporal_store(pk, &dst[idx]);
+                    } else {
+                        __builtin_nontemporal_store(u32x2{pk.x, pk.y}, reinterpret_cast<u32x2*>(&dst[idx]));
+                    }
+                } else {
+                    dst[idx] = pk;
                 }
             }
         }
@@ -314,10 +338,13 @@ int grid_for(int64_t blocks_needed) {
 template <int DT, int NV, int TPR>
 void launch_reg(const void* w, int64_t rows, int nvec, int8_t* q, float* scale, int64_t* zp, float* row_max,
                 hipStream_t st) {
-    const int64_t rows_per_block = kBlock / TPR;
-    const int grid = grid_for(miq::ceil_div(rows, rows_per_block));
-    quantize_rows_reg_kernel<DT, NV, TPR>
-        <<<grid, kBlock, 0, st>>>(static_cast<const uint4*>(w), rows, nvec, q, scale, zp, row_max);
+    constexpr int kThreads = TPR > kBlock ? TPR : kBlock;
+    // One row group per workgroup, no grid stride: with every load of a row issued up front, the
+    // hardware dispatcher refilling CUs keeps HBM busier than a resident-grid loop does.
+    const int64_t blocks = miq::ceil_div(rows, kThreads / TPR);
+    quantize_rows_reg_kernel<DT, NV, TPR, true>
+        <<<static_cast<unsigned>(blocks), kThreads, 0, st>>>(static_cast<const uint4*>(w), rows, nvec, q, scale, zp,
+                                                              row_max);
 }
 
 template <int DT>
@@ -330,26 +357,27 @@ int dispatch(const void* w, int64_t rows, int64_t cols, int8_t* q, float* scale,
         quantize_rows_stream_kernel<DT, false><<<grid_for(rows), kBlock, 0, st>>>(w, rows, cols, q, scale, zp, row_max);
         return miq::check_launch("quantize_rows_stream_kernel");
     }
-    const int64_t nvec = cols / kElems;
-    if (nvec <= 64) {
-        launch_reg<DT, 1, 64>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 128) {
-        launch_reg<DT, 2, 64>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 256) {
-        launch_reg<DT, 1, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 512) {
-        launch_reg<DT, 2, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 1024) {
-        launch_reg<DT, 4, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 2048) {
-        launch_reg<DT, 8, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 4096) {
-        launch_reg<DT, 16, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else if (nvec <= 7168) {
-        launch_reg<DT, 28, 256>(w, rows, static_cast<int>(nvec), q, scale, zp, row_max, st);
-    } else {
+    // Threads per row grow with the row so that a lane keeps 4-8 vectors (64-128 B) in flight.
+    const int nvec = static_cast<int>(cols / kElems);
+    if (cols / kElems > 8192) {
         quantize_rows_stream_kernel<DT, true><<<grid_for(rows), kBlock, 0, st>>>(w, rows, cols, q, scale, zp, row_max);
         return miq::check_launch("quantize_rows_stream_kernel");
+    } else if (nvec <= 64) {
+        launch_reg<DT, 1, 64>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 128) {
+        launch_reg<DT, 2, 64>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 256) {
+        launch_reg<DT, 4, 64>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 512) {
+        launch_reg<DT, 2, 256>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 1024) {
+        launch_reg<DT, 4, 256>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 2048) {
+        launch_reg<DT, 8, 256>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else if (nvec <= 4096) {
+        launch_reg<DT, 4, 1024>(w, rows, nvec, q, scale, zp, row_max, st);
+    } else {
+        launch_reg<DT, 8, 1024>(w, rows, nvec, q, scale, zp, row_max, st);
     }
     return miq::check_launch("quantize_rows_reg_kernel");
 }

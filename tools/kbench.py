@@ -45,7 +45,7 @@ def bench_quant():
         med, mn = timeit(fn, iters=3 * nbuf)
         es = ws[0].element_size()
         byts = rows * cols * (es + 1) + rows * 12
-        print(f"quant {rows}x{cols} {str(dt)[6:]}: med {med*1e3:.1f} us  {byts/med/1e9:.0f} GB/s (min {byts/mn/1e9:.0f})", flush=True)
+        print(f"quant {rows}x{cols} {str(dt)[6:]}: med {med*1e3:.1f} us  {byts/med/1e6:.0f} GB/s (best {byts/mn/1e6:.0f})", flush=True)
         del ws
 
 
