@@ -8,12 +8,14 @@
 //     one contiguous run starting at xp[b][ho*s+kh][wo*s][0]: no bounds checks, no gather.
 //   * weights: OIHW -> wp[Cout][KH][Lp], Lp = KW*Cp rounded up to 16, zero where padded.  The
 //     zero weights cancel whatever the activation run holds past KW*Cp.
-// K is walked in 16-byte chunks; a small LDS table maps chunk -> byte offset inside xp
-// relative to the pixel's base.  The main loop is the GEMM's: 128-byte K-tiles, LDS-DMA
+// K is walked in 16-byte chunks; chunk q lies in filter row q / cps at byte (q % cps) * 16 of
+// that row's run (cps = Lp / 16), relative to the pixel's base.  The main loop is the GEMM's: 128-byte K-tiles, LDS-DMA
 // staging, double buffering, v_mfma_i32_16x16x64_i8.  Pixels are the MFMA's first operand,
 // so a lane holds four consecutive pixels of one output channel: a 16-byte NCHW store.
 //
 // Replaces conv2d_kernel_int8 / conv2d_int8 (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:6-114).
+#include <cstdlib>
+
 #include "miq_common.h"
 #include "miq_gemm_core.h"
 
@@ -78,6 +80,125 @@ __global__ __launch_bounds__(256) void nhwc_pad_kernel(const int8_t* __restrict_
     }
 }
 
+// 4 x 4 byte transpose in registers: r[j] holds bytes (j, 0..3); d[i] gets bytes (0..3, i).
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint32_t (&d)[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u);  // r0.b0 r1.b0 r0.b1 r1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);  // r0.b2 r1.b2 r0.b3 r1.b3
+    const uint32_t u0 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u);
+    const uint32_t u1 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    d[0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+    d[1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+    d[2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+    d[3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+}
+
+// NCHW -> zero-padded NHWC, the image interior.  A workgroup moves 64 channels x 64 consecutive
+// pixels (flattened h*W + w, so short rows still fill a tile) of one image: every thread gathers a
+// 4-channel x 4-pixel byte block (one dword per channel plane when DWORD, i.e. H*W % 4 == 0 and an
+// aligned base; single bytes otherwise), transposes it in registers, and the dwords go through a
+// 4 KiB LDS tile laid out [pixel][channel] so that each thread can store 16 channel bytes of one
+// pixel.  The 16-byte groups of a tile row are XOR-ed with the pixel's dword index to spread the
+// writes over the banks.  The zero border is written by nhwc_border_kernel.
+template <bool DWORD>
+__global__ __launch_bounds__(256) void nhwc_interior_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ xp,
+                                                            int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
+                                                            int cblocks) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 16];
+    const int t = threadIdx.x;
+    const int HW = H * W;
+    const int p0 = (blockIdx.x / cblocks) * 64, c0 = (blockIdx.x % cblocks) * 64;
+    const int64_t b = blockIdx.y;
+    const int cspan = Cp - c0 < 64 ? Cp - c0 : 64;   // channel bytes this block owns per pixel (multiple of 4)
+    {
+        const int p4 = t & 15, cg = t >> 4;
+        uint32_t r[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + cg * 4 + j;
+            const int8_t* src = x + (b * Cin + c) * HW + p0 + p4 * 4;
+            r[j] = 0u;
+            if (c < Cin) {
+                if constexpr (DWORD) {
+                    if (p0 + p4 * 4 < HW) r[j] = *reinterpret_cast<const uint32_t*>(src);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p0 + p4 * 4 + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                }
+            }
+        }
+        transpose4x4_bytes(r, d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[(p4 * 4 + i) * 16 + (cg ^ ((p4 & 3) << 2))] = d[i];
+    }
+    __syncthreads();
+    const int pl = t >> 2, part = t & 3;
+    const int p = p0 + pl;
+    if (p < HW && part * 16 < cspan) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&tile[pl * 16 + ((part ^ ((pl >> 2) & 3)) << 2)]);
+        const int h = p / W, w = p - h * W;
+        int8_t* o = xp + ((b * Hp + h + pad) * Wp + w + pad) * Cp + c0 + part * 16;
+        if ((Cp & 15) == 0) {
+            *reinterpret_cast<uint4*>(o) = v;
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (part * 16 + k * 4 < cspan) *reinterpret_cast<uint32_t*>(o + k * 4) = vv[k];
+        }
+    }
+}
+
+// Zeros in the `pad` rows above and below and the `pad` columns left and right of every image.
+__global__ __launch_bounds__(256) void nhwc_border_kernel(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp,
+                                                          int pad, int64_t total) {
+    const int cdw = Cp >> 2;
+    const int per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int dw = static_cast<int>(idx % cdw);
+        const int e = static_cast<int>((idx / cdw) % per_image);
+        const int64_t b = idx / (static_cast<int64_t>(cdw) * per_image);
+        int hp, wp;
+        if (e < 2 * pad * Wp) {          // full rows: the first `pad` and the last `pad`
+            const int r = e / Wp;
+            hp = r < pad ? r : H + r;
+            wp = e - r * Wp;
+        } else {                         // side columns of the H interior rows
+            const int s = e - 2 * pad * Wp, r = s / (2 * pad), k = s - r * 2 * pad;
+            hp = r + pad;
+            wp = k < pad ? k : W + k;
+        }
+        reinterpret_cast<uint32_t*>(xp + ((b * Hp + hp) * Wp + wp) * Cp)[dw] = 0u;
+    }
+}
+
+// Same transform for Cin <= 4 (Cp == 4, e.g. an RGB stem): one thread per four pixels.
+__global__ __launch_bounds__(256) void nhwc_pad_c4_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin,
+                                                          int H, int W, int Hp, int Wp, int pad, int64_t total) {
+    const int W4 = W >> 2;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int w4 = static_cast<int>(idx % W4);
+        const int hp = static_cast<int>((idx / W4) % Hp);
+        const int64_t b = idx / (static_cast<int64_t>(W4) * Hp);
+        const int h = hp - pad;
+        uint32_t* orow = reinterpret_cast<uint32_t*>(xp) + (b * Hp + hp) * Wp;
+        uint32_t d[4] = {0u, 0u, 0u, 0u};
+        if (h >= 0 && h < H) {
+            uint32_t r[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < Cin) r[j] = *reinterpret_cast<const uint32_t*>(x + ((b * Cin + j) * H + h) * W + w4 * 4);
+            transpose4x4_bytes(r, d);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) orow[w4 * 4 + i + pad] = d[i];
+        if (w4 == 0)
+            for (int i = 0; i < pad; ++i) orow[i] = 0u;
+        if (w4 == W4 - 1)
+            for (int i = W + pad; i < Wp; ++i) orow[i] = 0u;
+    }
+}
+
 // OIHW -> wp[Cout][KH][Lp] with (kw, c) order inside a filter row and zero fill.
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
                                                                int64_t total, int Cin, int KH, int KW, int Cp, int L,
@@ -109,6 +230,7 @@ struct ConvArgs {
     int sx;                   // stride*Cp: bytes between horizontally adjacent output pixels' windows
     int sy;                   // stride*Wp*Cp
     int cps;                  // 16-byte chunks per filter row (Lp / 16)
+    uint32_t cps_magic;       // floor(2^32 / cps) + 1: q / cps == umulhi(q, cps_magic) for q < 2^16, cps > 1
     uint32_t xp_bytes, wp_bytes;
     int tiles_m, tiles_n;
 };
@@ -142,7 +264,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     constexpr int kPiecesM = BM / 8;
     constexpr int kItersM = (kPiecesM + NWAVES - 1) / NWAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* table = reinterpret_cast<int*>(smem + 2 * STAGE);  // chunk -> byte offset from the pixel base
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -153,7 +274,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int nchunks = g.Kp / kChunk;
-    for (int q = threadIdx.x; q < nchunks; q += 64 * NWAVES) table[q] = (q / g.cps) * g.row_stride + (q % g.cps) * kChunk;
 
     // Base offset in xp of the pixel each of this lane's staging rows belongs to.
     const int r_in = lane >> 3, slot = lane & 7;
@@ -178,8 +298,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-    __syncthreads();  // table visible
-
     auto stage_pixels = [&](char* tile, int kt) {
 #pragma unroll
         for (int i = 0; i < kItersM; ++i) {
@@ -187,8 +305,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
             if (kPiecesM % NWAVES != 0 && piece >= kPiecesM) break;
             const int r = piece * 8 + r_in;
             const int q = kt * kChunksPerRow + (slot ^ ((r >> 1) & 7));
+            // chunk q of the K axis = filter row q / cps, byte (q % cps) * 16 of that row's run
+            const int kh = g.cps == 1 ? q : static_cast<int>(__umulhi(static_cast<uint32_t>(q), g.cps_magic));
             uint32_t off = kOob;
-            if (q < nchunks && pix[i] != kOob) off = pix[i] + table[q];
+            if (q < nchunks && pix[i] != kOob) off = pix[i] + kh * g.row_stride + (q - kh * g.cps) * kChunk;
             dma16(rx, tile + piece * (8 * kTileK), off);
         }
     };
@@ -285,7 +405,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tile(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
-    const int lds = 2 * (BM + BN) * kTileK + static_cast<int>(round_up(g.Kp / kChunk * 4, 16));
+    const int lds = 2 * (BM + BN) * kTileK;
     auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
@@ -296,6 +416,19 @@ template <int OUT>
 int launch(const ConvArgs& g, hipStream_t st) {
     // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
     auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
+    const char* force = getenv("MIQ_CONV_TILE");   // developer A/B switch
+    if (force) {
+        switch (force[0]) {
+            case '0': return launch_tile<256, 256, 2, 4, OUT>(g, st);
+            case '1': return launch_tile<256, 128, 2, 4, OUT>(g, st);
+            case '2': return launch_tile<256, 64, 4, 2, OUT>(g, st);
+            case '3': return launch_tile<128, 128, 2, 2, OUT>(g, st);
+            case '4': return launch_tile<128, 64, 2, 2, OUT>(g, st);
+            case '5': return launch_tile<64, 64, 2, 2, OUT>(g, st);
+            case '6': return launch_tile<128, 256, 2, 4, OUT>(g, st);
+            default: break;
+        }
+    }
     if (g.Cout > 128 && tiles(256, 256) >= 200) return launch_tile<256, 256, 2, 4, OUT>(g, st);
     if (g.Cout > 64 && tiles(256, 128) >= 200) return launch_tile<256, 128, 2, 4, OUT>(g, st);
     if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
@@ -345,8 +478,28 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         const int cblocks = static_cast<int>(miq::ceil_div(G.Cp, 64));
         dim3 grid(static_cast<unsigned>(miq::ceil_div(G.Wp, 64) * cblocks), static_cast<unsigned>(G.Hp),
                   static_cast<unsigned>(B));
-        nhwc_pad_kernel<<<grid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp,
-                                              (int)pad, cblocks);
+        if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4) {
+            const int64_t total4 = B * G.Hp * (W / 4);
+            const int g4 = static_cast<int>(total4 / 256 + 1 < (1 << 20) ? total4 / 256 + 1 : (1 << 20));
+            nhwc_pad_c4_kernel<<<g4, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)pad, total4);
+        } else if (H * W < (1ll << 30)) {
+            dim3 fgrid(static_cast<unsigned>(miq::ceil_div(H * W, 64) * cblocks), static_cast<unsigned>(B));
+            if ((H * W) % 4 == 0 && miq::aligned(x, 4))
+                nhwc_interior_kernel<true><<<fgrid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp,
+                                                                  (int)G.Cp, (int)pad, cblocks);
+            else
+                nhwc_interior_kernel<false><<<fgrid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp,
+                                                                   (int)G.Cp, (int)pad, cblocks);
+            if (pad > 0) {
+                if (int rc = miq::check_launch("nhwc_interior_kernel")) return rc;
+                const int64_t btotal = B * (2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 4);
+                const int bg = static_cast<int>(btotal / 256 + 1 < 65536 ? btotal / 256 + 1 : 65536);
+                nhwc_border_kernel<<<bg, 256, 0, st>>>(xp, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, btotal);
+            }
+        } else {
+            nhwc_pad_kernel<<<grid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp,
+                                                  (int)pad, cblocks);
+        }
         if (int rc = miq::check_launch("nhwc_pad_kernel")) return rc;
         const int64_t total = G.wp_bytes;
         const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
@@ -372,6 +525,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
     a.sx = static_cast<int>(stride * G.Cp);
     a.sy = static_cast<int>(stride * G.Wp * G.Cp);
     a.cps = static_cast<int>(G.Lp / kChunk);
+    a.cps_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(a.cps)) + 1u;
     a.xp_bytes = static_cast<uint32_t>(G.xp_bytes);
     a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
     switch (out_dtype) {

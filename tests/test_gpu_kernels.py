@@ -238,6 +238,10 @@ CONV_SHAPES = [
     (3, 16, 14, 14, 32, 3, 1, 1), (2, 64, 14, 14, 64, 3, 1, 1), (2, 64, 15, 15, 128, 3, 2, 1),
     (2, 64, 14, 14, 128, 1, 2, 0), (4, 128, 7, 7, 256, 3, 1, 1), (1, 5, 6, 7, 3, 2, 1, 0), (1, 1, 4, 4, 1, 3, 1, 2),
     (2, 3, 30, 30, 64, 7, 2, 3),
+    # W % 4 == 0: the dword-transposing re-layout kernels (channel counts that are / are not multiples of 16,
+    # more than one 64-channel block, more than one 64-pixel tile per row)
+    (2, 8, 12, 12, 16, 3, 1, 1), (1, 70, 8, 72, 32, 3, 1, 1), (2, 20, 16, 16, 24, 3, 2, 1),
+    (1, 130, 8, 8, 16, 1, 1, 0), (2, 4, 8, 132, 8, 3, 1, 2), (1, 2, 16, 16, 4, 5, 1, 2),
 ]
 
 
