@@ -41,6 +41,15 @@ def event_times(fn, iters):
     return [s.elapsed_time(e) for s, e in evs]
 
 
+def profiled_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(K, N, sample_rows, seed):
     """Reference CPU path on a bounded sample: quantize a [1024, K] slab of the weight with the
     reference's row loop, then weight-only forward of `sample_rows` rows against the full weight."""
@@ -193,10 +202,11 @@ def main():
                 "peak": PEAK_INT8_TOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_INT8_TOPS, 4),
-                "traffic": None,
-                "kernel": "gemm_i8_kernel<256,256,2,4>",
+                "traffic": profiled_traffic("gemm_i8_256_kernel") if S == 8192 else None,
+                "kernel": "gemm_i8_256_kernel",
                 "kernel_ms": round(k_ms, 4),
-                "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch",
+                "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch; "
+                        "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/",
             },
             "extra": {
                 "quantizer": {
@@ -205,7 +215,9 @@ def main():
                     "kernel_ms": round(q_ms, 4),
                     "roofline": {"bound": "hbm", "achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(q_bytes / (q_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None},
+                                 "frac": round(q_bytes / (q_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "traffic": profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None,
+                                 "algorithmic_bytes": q_bytes},
                 },
             },
         }
