@@ -8,7 +8,8 @@ epilogue) at M = N = K = 8192 per GPU, the shape BASELINE.json quotes its target
 One step = one forward of the layer on int8 activations already resident in HBM, with weights
 produced by the per-channel quantizer from seeded fp32 data.  With N > 1 each rank owns 8192
 output channels of a [8192*N, 8192] layer (weak scaling) and a step also all-gathers the
-[8192, 8192] fp32 output blocks over RCCL, so every rank ends with the full [8192, 8192*N] output.
+[8192, 8192] fp32 output blocks over RCCL, so every rank ends with the full [8192, 8192*N] output;
+the gather of one step overlaps the GEMM of the next (independent layers of a stack).
 
 Rank 0 prints ONE JSON line.  `value` is whole-job int8 TOPS (2*M*N*K integer operations per
 layer).  `roofline` prices the GEMM kernel against the dense int8 MFMA peak with the kernel's own
@@ -137,21 +138,26 @@ def main():
 
     layer = ColumnShardedLinear(wq, scale, bias_local, n_total, out_dtype=torch.float32)
 
-    def step():
-        y = layer.local_forward(x)
-        buf, work = layer.gather_async(y)
-        if work is not None:
-            work.wait()
-        return buf
+    def run_steps(n):
+        """n forwards of the layer.  The all-gather of step i runs on RCCL's stream while the GEMM of
+        step i+1 runs on the compute stream (the steps are independent layers of a stack); at most two
+        gathers are in flight, and every one has completed when this returns."""
+        pending = None
+        for _ in range(n):
+            y = layer.local_forward(x)
+            _, work = layer.gather_async(y)
+            if pending is not None:
+                pending.wait()
+            pending = work
+        if pending is not None:
+            pending.wait()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

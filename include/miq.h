@@ -114,8 +114,9 @@ int miq_epilogue_channels_f32(const float* y, const float* bias, const float* al
  * bias: fp32 [N] or NULL (no add).  alpha: fp32 [N] (required unless out_dtype = MIQ_I32).
  * out: [M,N] row-major of out_dtype MIQ_F32 | MIQ_BF16 | MIQ_I32.
  * workspace: device scratch of at least miq_gemm_i8_workspace(...) bytes, 256-byte
- * aligned (only MIQ_W_KN needs any: the weight is re-laid [N,K] there first); may be NULL
- * when that size is 0.  The caller may cache the re-laid weight: see miq_transpose_i8.
+ * aligned; may be NULL when that size is 0.  It holds the weight re-laid [N,K] (MIQ_W_KN
+ * only; the caller may instead cache the re-laid weight, see miq_transpose_i8) and, for
+ * thin problems (few output tiles, deep K), the int32 slabs of a split-K run.
  */
 size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K);
 int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,

@@ -26,6 +26,7 @@ struct GemmArgs {
     float beta;
     int M, N, K;
     int tiles_m, tiles_n;
+    int kt_per_split;  // K-tiles each blockIdx.y slice sums (split-K: raw int32 slabs out); 0 = all of K
 };
 
 // Fills one LDS stage: rows [row0, row0 + ROWS) x K-tile kt of a [nrows, K] int8 matrix.
@@ -78,19 +79,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-    const int nt = (g.K + kTileK - 1) / kTileK;
+    // Split-K: slice blockIdx.y sums K-tiles [kt0, kt0 + nt) into its own int32 slab of the output.
+    const int nt_all = (g.K + kTileK - 1) / kTileK;
+    const int kt0 = g.kt_per_split ? static_cast<int>(blockIdx.y) * g.kt_per_split : 0;
+    const int nt = g.kt_per_split ? (nt_all - kt0 < g.kt_per_split ? nt_all - kt0 : g.kt_per_split) : nt_all;
+    if (g.kt_per_split) g.out = static_cast<int*>(g.out) + static_cast<size_t>(blockIdx.y) * g.M * g.N;
     const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
 
-    stage_tile<BM, NWAVES>(ra, smem, m0, g.M, g.K, 0, wave, lane);
-    stage_tile<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.N, g.K, 0, wave, lane);
+    stage_tile<BM, NWAVES>(ra, smem, m0, g.M, g.K, kt0, wave, lane);
+    stage_tile<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.N, g.K, kt0, wave, lane);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * STAGE;
         if (t + 1 < nt) {
             char* nxt = smem + ((t + 1) & 1) * STAGE;
-            stage_tile<BM, NWAVES>(ra, nxt, m0, g.M, g.K, t + 1, wave, lane);
-            stage_tile<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.N, g.K, t + 1, wave, lane);
+            stage_tile<BM, NWAVES>(ra, nxt, m0, g.M, g.K, kt0 + t + 1, wave, lane);
+            stage_tile<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.N, g.K, kt0 + t + 1, wave, lane);
         }
         const char* at = cur + wm * WM * kTileK;
         const char* wt = cur + BM * kTileK + wn * WN * kTileK;
@@ -473,6 +478,67 @@ __global__ __launch_bounds__(256) void gemm_i8_any_kernel(GemmArgs g) {
     }
 }
 
+// Sums the split-K slabs and applies the epilogue: out[m,n] = ((sum_s slab[s][m][n]) + bias[n]) * alpha[n] + beta.
+template <int OUT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const int* __restrict__ slabs, int splits, GemmArgs g) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        int sum = 0;
+        for (int s = 0; s < splits; ++s) sum += slabs[s * total + idx];
+        const int n = static_cast<int>(idx % g.N);
+        if constexpr (OUT == kOutI32) {
+            static_cast<int*>(g.out)[idx] = sum;
+        } else {
+            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
+            if constexpr (OUT == kOutF32) {
+                static_cast<float*>(g.out)[idx] = y;
+            } else {
+                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+            }
+        }
+    }
+}
+
+// Tile and split-K choice for shapes that do not fill the chip with 256 x 256 tiles.  Thin
+// problems (few output tiles, deep K) are cut along K so that a few hundred workgroups stream the
+// weight concurrently; the slices write int32 slabs that splitk_reduce_kernel sums.
+struct GemmPlan {
+    int bm;      // activation rows per tile: 256 (pipelined kernel), 128, 64, 32 or 16
+    int bn;
+    int splits;  // 1 = no split
+    int kt_per_split;
+};
+
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
+    GemmPlan p{256, 256, 1, 0};
+    const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
+    if (M > 128 && big_tiles >= 192) return p;
+    if (M > 64) {
+        p.bm = 128; p.bn = 128;
+    } else if (M > 32) {
+        p.bm = 64; p.bn = 64;
+    } else if (M > 16) {
+        p.bm = 32; p.bn = 64;
+    } else {
+        p.bm = 16; p.bn = 64;
+    }
+    const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
+    const int64_t nt = ceil_div(K, kTileK);
+    int64_t splits = 1;
+    if (tiles < 160 && nt >= 16) {
+        splits = ceil_div(512, tiles);                       // aim at ~2 workgroups per CU
+        if (splits > nt / 8) splits = nt / 8;                // at least 8 K-tiles (1 KiB of K) per slice
+        if (splits > K / (8 * M)) splits = K / (8 * M);      // slab traffic (2 * 4*splits*M*N) <= weight bytes N*K
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    if (splits > 1) {
+        p.kt_per_split = static_cast<int>(ceil_div(nt, splits));
+        p.splits = static_cast<int>(ceil_div(nt, p.kt_per_split));
+    }
+    return p;
+}
+
 __global__ __launch_bounds__(256) void transpose_i8_kernel(const int8_t* __restrict__ src, int64_t rows,
                                                            int64_t cols, int8_t* __restrict__ dst) {
     __shared__ int8_t tile[64][65];
@@ -491,20 +557,33 @@ __global__ __launch_bounds__(256) void transpose_i8_kernel(const int8_t* __restr
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
-int launch_tile(GemmArgs g, hipStream_t st) {
+int launch_tile(GemmArgs g, hipStream_t st, int splits = 1, int kt_per_split = 0, int* slabs = nullptr) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
     constexpr int kLds = 2 * (BM + BN) * kTileK;
-    auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
-    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_gemm_i8: too many tiles");
+    if (splits > 1) {
+        GemmArgs part = g;
+        part.out = slabs;
+        part.kt_per_split = kt_per_split;
+        auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, kOutI32>;
+        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+        kern<<<dim3(static_cast<unsigned>(nwg), static_cast<unsigned>(splits)), 64 * WAVES_M * WAVES_N, kLds, st>>>(part);
+        if (int rc = check_launch("gemm_i8_kernel (split-K)")) return rc;
+        const int64_t total = static_cast<int64_t>(g.M) * g.N;
+        const int rgrid = static_cast<int>(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+        splitk_reduce_kernel<OUT><<<rgrid, 256, 0, st>>>(slabs, splits, g);
+        return check_launch("splitk_reduce_kernel");
+    }
+    auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
     return check_launch("gemm_i8_kernel");
 }
 
 template <int OUT>
-int launch(GemmArgs g, bool mfma_ok, hipStream_t st) {
+int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     if (!mfma_ok) {
         const int64_t total = static_cast<int64_t>(g.M) * g.N;
         const int grid = static_cast<int>(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
@@ -513,8 +592,8 @@ int launch(GemmArgs g, bool mfma_ok, hipStream_t st) {
     }
     // Tile choice: the 256x256 tile (8 waves, 128 KiB LDS) once both dimensions can fill the
     // chip with it; smaller tiles keep more workgroups in flight for thin problems.
-    const int64_t big_tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
-    if (g.M > 128 && big_tiles >= 192) {
+    const GemmPlan plan = plan_gemm(g.M, g.N, g.K);
+    if (plan.bm == 256) {
         const char* simple = getenv("MIQ_GEMM_SIMPLE");   // developer A/B switch
         if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
         g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
@@ -535,18 +614,29 @@ int launch(GemmArgs g, bool mfma_ok, hipStream_t st) {
         kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
         return check_launch("gemm_i8_256_kernel");
     }
-    if (g.M > 64) return launch_tile<128, 128, 2, 2, OUT>(g, st);
-    if (g.M > 32) return launch_tile<64, 64, 2, 2, OUT>(g, st);
-    if (g.M > 16) return launch_tile<32, 64, 1, 4, OUT>(g, st);
-    return launch_tile<16, 64, 1, 4, OUT>(g, st);
+    if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+    if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+    if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+    return launch_tile<16, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
 }
 
 }  // namespace
 
+namespace {
+// Workspace = [re-laid [N,K] weight, only for MIQ_W_KN][split-K int32 slabs, only for thin problems].
+size_t transposed_bytes(int w_layout, int64_t N, int64_t K) {
+    return w_layout == MIQ_W_KN ? static_cast<size_t>(miq::round_up(N * K, 256)) : 0;
+}
+size_t slab_bytes(int64_t M, int64_t N, int64_t K) {
+    if (K % 16 != 0) return 0;
+    const GemmPlan p = plan_gemm(M, N, K);
+    return p.splits > 1 ? static_cast<size_t>(miq::round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
+}
+}  // namespace
+
 extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K) {
-    (void)M;
-    if (w_layout != MIQ_W_KN || N <= 0 || K <= 0) return 0;
-    return static_cast<size_t>(miq::round_up(N * K, 256));
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return transposed_bytes(w_layout, N, K) + slab_bytes(M, N, K);
 }
 
 extern "C" int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream) {
@@ -578,27 +668,34 @@ extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64
                 "miq_gemm_i8: out/alpha/bias not aligned to their element size");
     hipStream_t st = miq::as_stream(stream);
 
-    if (w_layout == MIQ_W_KN && K > 0) {
+    int* slabs = nullptr;
+    if (K > 0) {
         const size_t need = miq_gemm_i8_workspace(w_layout, M, N, K);
-        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
-                    "miq_gemm_i8: [K,N] weights need %zu bytes of workspace (got %zu)", need, workspace_bytes);
-        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
-        int rc = miq_transpose_i8(W, K, N, static_cast<int8_t*>(workspace), stream);
-        if (rc != MIQ_OK) return rc;
-        W = static_cast<const int8_t*>(workspace);
+        if (need) {
+            MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                        "miq_gemm_i8: this call needs %zu bytes of workspace (got %zu): see miq_gemm_i8_workspace", need,
+                        workspace_bytes);
+            MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
+        }
+        if (w_layout == MIQ_W_KN) {
+            int rc = miq_transpose_i8(W, K, N, static_cast<int8_t*>(workspace), stream);
+            if (rc != MIQ_OK) return rc;
+            W = static_cast<const int8_t*>(workspace);
+        }
+        if (slab_bytes(M, N, K)) slabs = reinterpret_cast<int*>(static_cast<char*>(workspace) + transposed_bytes(w_layout, N, K));
     }
 
-    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0};
+    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0, 0};
     // 16-byte vector stores in the epilogue need out rows 16-byte aligned when N % 4 == 0.
     const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
     const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(A, 16) && miq::aligned(W, 16) && out_vec_ok &&
                          (out_dtype == MIQ_I32 || (miq::aligned(alpha, 4) && miq::aligned(bias, 4)));
     switch (out_dtype) {
         case MIQ_F32:
-            return launch<kOutF32>(g, mfma_ok, st);
+            return launch<kOutF32>(g, mfma_ok, slabs, st);
         case MIQ_BF16:
-            return launch<kOutBF16>(g, mfma_ok, st);
+            return launch<kOutBF16>(g, mfma_ok, slabs, st);
         default:
-            return launch<kOutI32>(g, mfma_ok, st);
+            return launch<kOutI32>(g, mfma_ok, slabs, st);
     }
 }

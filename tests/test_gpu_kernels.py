@@ -134,6 +134,8 @@ GEMM_SHAPES = [
     (128, 128, 128), (129, 257, 400), (200, 520, 384), (256, 256, 256), (300, 4096, 256), (512, 768, 1024),
     (1024, 4096, 2048),  # the reference's own test shape (linear_int8/test.py:5-6)
     (37, 130, 300), (3, 4, 6), (5, 48, 64),  # K not a multiple of 16 -> element-wise kernel
+    # thin problems: split along K into int32 slabs + reduce kernel
+    (1, 256, 4096), (16, 1024, 14336), (40, 520, 8192), (100, 300, 2064), (256, 512, 8192), (200, 128, 16384),
 ]
 
 
