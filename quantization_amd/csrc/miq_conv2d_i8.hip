@@ -416,19 +416,6 @@ template <int OUT>
 int launch(const ConvArgs& g, hipStream_t st) {
     // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
     auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
-    const char* force = getenv("MIQ_CONV_TILE");   // developer A/B switch
-    if (force) {
-        switch (force[0]) {
-            case '0': return launch_tile<256, 256, 2, 4, OUT>(g, st);
-            case '1': return launch_tile<256, 128, 2, 4, OUT>(g, st);
-            case '2': return launch_tile<256, 64, 4, 2, OUT>(g, st);
-            case '3': return launch_tile<128, 128, 2, 2, OUT>(g, st);
-            case '4': return launch_tile<128, 64, 2, 2, OUT>(g, st);
-            case '5': return launch_tile<64, 64, 2, 2, OUT>(g, st);
-            case '6': return launch_tile<128, 256, 2, 4, OUT>(g, st);
-            default: break;
-        }
-    }
     if (g.Cout > 128 && tiles(256, 256) >= 200) return launch_tile<256, 256, 2, 4, OUT>(g, st);
     if (g.Cout > 64 && tiles(256, 128) >= 200) return launch_tile<256, 128, 2, 4, OUT>(g, st);
     if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
@@ -436,7 +423,50 @@ int launch(const ConvArgs& g, hipStream_t st) {
     return launch_tile<128, 64, 2, 2, OUT>(g, st);
 }
 
+// dst[c][r] = src[r][c], any shape, byte accesses through a padded LDS tile.
+__global__ __launch_bounds__(256) void transpose_bytes_kernel(const int8_t* __restrict__ src, int64_t rows,
+                                                              int64_t cols, int8_t* __restrict__ dst) {
+    __shared__ int8_t tile[64][65];
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64, c0 = static_cast<int64_t>(blockIdx.x) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;
+        if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(r0 + r) * cols + c0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;  // r: src column, c: src row
+        if (c0 + r < cols && r0 + c < rows) dst[(c0 + r) * rows + r0 + c] = tile[c][r];
+    }
+}
+
 }  // namespace
+
+// A [rows, cols] -> [cols, rows] transpose is the channels-last re-layout of one "image" with
+// `rows` channels and `cols` pixels and no border, so the register-transposing kernel serves both.
+extern "C" int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream) {
+    MIQ_REQUIRE(rows >= 0 && cols >= 0, MIQ_EINVAL, "miq_transpose_i8: negative size");
+    if (rows == 0 || cols == 0) return MIQ_OK;
+    MIQ_REQUIRE(src && dst, MIQ_EINVAL, "miq_transpose_i8: null pointer");
+    MIQ_REQUIRE(rows < (1ll << 31) && cols < (1ll << 30), MIQ_ERANGE, "miq_transpose_i8: at most 2^31 x 2^30");
+    hipStream_t st = miq::as_stream(stream);
+    if (rows % 4 == 0 && miq::aligned(dst, 16) && miq::ceil_div(cols, 64) * miq::ceil_div(rows, 64) < (1ll << 31)) {
+        const int cblocks = static_cast<int>(miq::ceil_div(rows, 64));
+        dim3 grid(static_cast<unsigned>(miq::ceil_div(cols, 64) * cblocks), 1);
+        if (cols % 4 == 0 && miq::aligned(src, 4))
+            nhwc_interior_kernel<true><<<grid, 256, 0, st>>>(src, dst, (int)rows, 1, (int)cols, 1, (int)cols, (int)rows, 0,
+                                                             cblocks);
+        else
+            nhwc_interior_kernel<false><<<grid, 256, 0, st>>>(src, dst, (int)rows, 1, (int)cols, 1, (int)cols, (int)rows, 0,
+                                                              cblocks);
+        return miq::check_launch("nhwc_interior_kernel (transpose)");
+    }
+    MIQ_REQUIRE(miq::ceil_div(rows, 64) < 65536, MIQ_ERANGE, "miq_transpose_i8: more than 4M rows with rows % 4 != 0");
+    dim3 grid(static_cast<unsigned>(miq::ceil_div(cols, 64)), static_cast<unsigned>(miq::ceil_div(rows, 64)));
+    transpose_bytes_kernel<<<grid, 256, 0, st>>>(src, rows, cols, dst);
+    return miq::check_launch("transpose_bytes_kernel");
+}
 
 extern "C" size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
                                           int64_t KW, int64_t stride, int64_t pad) {

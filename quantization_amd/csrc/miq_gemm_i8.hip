@@ -539,23 +539,6 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void transpose_i8_kernel(const int8_t* __restrict__ src, int64_t rows,
-                                                           int64_t cols, int8_t* __restrict__ dst) {
-    __shared__ int8_t tile[64][65];
-    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64, c0 = static_cast<int64_t>(blockIdx.x) * 64;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;
-        if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(r0 + r) * cols + c0 + c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = threadIdx.x + i * 256, r = idx >> 6, c = idx & 63;  // r: src column, c: src row
-        if (c0 + r < cols && r0 + c < rows) dst[(c0 + r) * rows + r0 + c] = tile[c][r];
-    }
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tile(GemmArgs g, hipStream_t st, int splits = 1, int kt_per_split = 0, int* slabs = nullptr) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
@@ -639,15 +622,6 @@ extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int6
     return transposed_bytes(w_layout, N, K) + slab_bytes(M, N, K);
 }
 
-extern "C" int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream) {
-    MIQ_REQUIRE(rows >= 0 && cols >= 0, MIQ_EINVAL, "miq_transpose_i8: negative size");
-    if (rows == 0 || cols == 0) return MIQ_OK;
-    MIQ_REQUIRE(src && dst, MIQ_EINVAL, "miq_transpose_i8: null pointer");
-    MIQ_REQUIRE(miq::ceil_div(rows, 64) < 65536, MIQ_ERANGE, "miq_transpose_i8: more than 4M rows");
-    dim3 grid(static_cast<unsigned>(miq::ceil_div(cols, 64)), static_cast<unsigned>(miq::ceil_div(rows, 64)));
-    transpose_i8_kernel<<<grid, 256, 0, miq::as_stream(stream)>>>(src, rows, cols, dst);
-    return miq::check_launch("transpose_i8_kernel");
-}
 
 extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
                            const float* bias, const float* alpha, float beta, void* out, int out_dtype,

@@ -200,8 +200,9 @@ def test_gemm_kn_layout_is_linear_w8a8(N):
     np.testing.assert_array_equal(out.cpu().numpy(), OC.linear_w8a8(a.numpy(), b.numpy()))
     t = N.transpose_i8(b.cuda())
     np.testing.assert_array_equal(t.cpu().numpy(), b.numpy().T)
-    odd = rand_i8((67, 129), 8)
-    np.testing.assert_array_equal(N.transpose_i8(odd.cuda()).cpu().numpy(), odd.numpy().T)
+    for shape in [(67, 129), (100, 130), (2048, 4096), (72, 64), (4, 4), (1, 7), (260, 1)]:
+        m = rand_i8(shape, 8)
+        np.testing.assert_array_equal(N.transpose_i8(m.cuda()).cpu().numpy(), m.numpy().T, err_msg=str(shape))
 
 
 def test_gemm_errors(N):
