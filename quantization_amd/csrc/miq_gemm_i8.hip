@@ -597,6 +597,19 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
         return check_launch("gemm_i8_256_kernel");
     }
+    if (const char* force = getenv("MIQ_GEMM_TILE")) {   // developer A/B switch
+        switch (force[0]) {
+            case 'a': return launch_tile<128, 128, 2, 2, OUT>(g, st);
+            case 'b': return launch_tile<128, 64, 2, 2, OUT>(g, st);
+            case 'c': return launch_tile<64, 128, 2, 2, OUT>(g, st);
+            case 'd': return launch_tile<128, 128, 2, 4, OUT>(g, st);
+            case 'e': return launch_tile<256, 128, 2, 4, OUT>(g, st);
+            case 'f': return launch_tile<256, 64, 4, 2, OUT>(g, st);
+            case 'g': return launch_tile<64, 64, 2, 2, OUT>(g, st);
+            case 'h': return launch_tile<128, 64, 4, 2, OUT>(g, st);
+            default: break;
+        }
+    }
     if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
