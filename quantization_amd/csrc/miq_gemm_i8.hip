@@ -210,6 +210,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
         asm volatile("" ::: "memory");      \
     } while (0)
 
+// All but the 8 youngest DMA instructions (four half-tiles) have landed.  (ABL bit 32: timing-only
+// build that keeps just two half-tiles in flight, to measure what the depth is worth.)
+#define MIQ_WAIT_DMA()                                            \
+    do {                                                          \
+        if constexpr ((ABL & 32) != 0)                            \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      \
+        else                                                      \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
+    } while (0)
+
 template <int OUT, int VARIANT, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     constexpr int kHalf = 128 * kTileK;   // one half-tile: 128 rows x 128 B
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     stage_half(ra, smem + 1 * kHalf, abase[1], 0);
     stage_half(ra, smem + kBuf + 0 * kHalf, abase[0], 1);
     stage_half(rw, smem + kBuf + 2 * kHalf, wbase[0], 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0(0), W0(0); in VARIANT 1 also the rest of tile 0
+    MIQ_WAIT_DMA();   // A0(0), W0(0); in VARIANT 1 also the rest of tile 0
     if constexpr (VARIANT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     MIQ_BARRIER();
     // Waves 4-7 (the second wave on each SIMD) run one barrier behind waves 0-3: while one group
@@ -310,6 +320,10 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i) af[ks][i] = lds_read16(half + a_frag + i * 16 * kTileK + lo[ks]);
     };
     auto mma = [&](v4i (&c)[4][2], const v4i (&wf)[2][2]) {
+        if (ABL & 16) {   // timing-only build: no MFMAs, operands kept live
+            asm volatile("" :: "v"(wf[0][0]), "v"(wf[1][1]), "v"(af[0][0]), "v"(af[1][3]));
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             read_w(wf0, cur + 2 * kHalf);
             read_a(cur + 0 * kHalf);
             stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W1(t) has landed
+            MIQ_WAIT_DMA();   // W1(t) has landed
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
             mma(acc[0][0], wf0);
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
 
             read_w(wf1, cur + 3 * kHalf);
             stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A1(t)
+            MIQ_WAIT_DMA();   // A1(t)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
             mma(acc[0][1], wf1);
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
 
             read_a(cur + 1 * kHalf);
             stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0(t+1)
+            MIQ_WAIT_DMA();   // A0(t+1)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
             mma(acc[1][1], wf1);
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             MIQ_BARRIER();
 
             stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W0(t+1)
+            MIQ_WAIT_DMA();   // W0(t+1)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
             mma(acc[1][0], wf0);
@@ -587,7 +601,13 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         const char* abl = getenv("MIQ_GEMM_ABL");
         if (abl && OUT == kOutF32) {
             if (abl[0] == '1') kern = gemm_i8_256_kernel<OUT, 0, 1>;
-            if (abl[0] == '2') kern = gemm_i8_256_kernel<OUT, 0, 2>;
+            if (abl[0] == '6') kern = gemm_i8_256_kernel<OUT, 0, 8>;
+            if (abl[0] == '7') kern = gemm_i8_256_kernel<OUT, 0, 16>;
+            if (abl[0] == '8') kern = gemm_i8_256_kernel<OUT, 0, 16 + 2>;
+            if (abl[0] == '9') kern = gemm_i8_256_kernel<OUT, 0, 16 + 2 + 8>;
+            if (abl[0] == 'a') kern = gemm_i8_256_kernel<OUT, 0, 32 + 16 + 2>;
+            if (abl[0] == 'b') kern = gemm_i8_256_kernel<OUT, 0, 32>;
+            if (abl[0] == 'c') kern = gemm_i8_256_kernel<OUT, 0, 32 + 2>;
             if (abl[0] == '3') kern = gemm_i8_256_kernel<OUT, 0, 3>;
             if (abl[0] == '4') kern = gemm_i8_256_kernel<OUT, 0, 4 + 2>;
             if (abl[0] == '5') kern = gemm_i8_256_kernel<OUT, 0, 8 + 2>;
