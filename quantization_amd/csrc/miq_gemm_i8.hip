@@ -27,6 +27,7 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int kt_per_split;  // K-tiles each blockIdx.y slice sums (split-K: raw int32 slabs out); 0 = all of K
+    unsigned* stamps;  // timing-only builds: per-wave cycle totals of the main loop's segments
 };
 
 // Fills one LDS stage: rows [row0, row0 + ROWS) x K-tile kt of a [nrows, K] int8 matrix.
@@ -178,6 +179,74 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     }
 }
 
+// Epilogue of a 256 x 256 tile held as acc[qm][qn][i][j] by 8 waves (2 x 4).  D[i][j] of a fragment:
+// i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
+template <int OUT>
+__device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&acc)[2][2][4][2], int m0, int n0, int wm,
+                                               int wn, int lane) {
+    const bool vec_ok = (g.N & 3) == 0;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
+            float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (OUT != kOutI32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) {
+                        al[e] = g.alpha[n + e];
+                        if (g.bias) bi[e] = g.bias[n + e];
+                    }
+            }
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
+                    if (m >= g.M || n >= g.N) continue;
+                    const v4i a = acc[qm][qn][i][j];
+                    const size_t idx = static_cast<size_t>(m) * g.N + n;
+                    if constexpr (OUT == kOutI32) {
+                        int* o = static_cast<int*>(g.out) + idx;
+                        if (vec_ok && n + 3 < g.N) {
+                            *reinterpret_cast<v4i*>(o) = a;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < g.N) o[e] = a[e];
+                        }
+                    } else {
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
+                        if constexpr (OUT == kOutF32) {
+                            float* o = static_cast<float*>(g.out) + idx;
+                            if (vec_ok && n + 3 < g.N) {
+                                *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < g.N) o[e] = y[e];
+                            }
+                        } else {
+                            uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
+                            if (vec_ok && n + 3 < g.N) {
+                                uint2 p;
+                                p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
+                                p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
+                                *reinterpret_cast<uint2*>(o) = p;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
+                            }
+                        }
+                    }
+                }
+        }
+}
+
 // ---------------------------------------------------------------------------------------
 // 256 x 256 tile, software-pipelined: the kernel large GEMMs run on.
 //
@@ -190,10 +259,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
 // A K-tile is four phases of 16 MFMAs (one quadrant each).  A phase is a LOAD segment (LDS
 // fragment reads + one half-tile of LDS-DMA for a later K-tile + a counted vmcnt), a raw barrier,
 // an MFMA segment, a raw barrier:
-//   P1: read W0,A0 of tile t | DMA W1(t+1) | vmcnt(8) | barrier | MFMA quadrant (0,0) | barrier
+//   P1: read W0 of tile t    | DMA W1(t+1) | vmcnt(8) | barrier | MFMA quadrant (0,0) | barrier
 //   P2: read W1              | DMA A1(t+1) | vmcnt(8) | barrier | MFMA (0,1)          | barrier
 //   P3: read A1              | DMA A0(t+2) | vmcnt(8) | barrier | MFMA (1,1)          | barrier
-//   P4:                      | DMA W0(t+2) | vmcnt(8) | barrier | MFMA (1,0)          | barrier
+//   P4: read A0 of tile t+1  | DMA W0(t+2) | vmcnt(8) | barrier | MFMA (1,0)          | barrier
+// (A0 and A1 live in two register sets, so LDS reads per phase are 4, 4, 8, 8; VARIANT 0, kept for
+// timing experiments, reads A0 in P1 instead: 12, 4, 8, 0 with one register set.)
 // Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so while one group
 // is in an MFMA segment the other is in a LOAD segment and the matrix pipe is not left waiting.
 // Every wave issues exactly two DMA instructions per phase (tiles past K are fetched as
@@ -285,14 +356,13 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     stage_half(ra, smem + 1 * kHalf, abase[1], 0);
     stage_half(ra, smem + kBuf + 0 * kHalf, abase[0], 1);
     stage_half(rw, smem + kBuf + 2 * kHalf, wbase[0], 1);
-    MIQ_WAIT_DMA();   // A0(0), W0(0); in VARIANT 1 also the rest of tile 0
-    if constexpr (VARIANT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    MIQ_WAIT_DMA();   // A0(0), W0(0)
     MIQ_BARRIER();
     // Waves 4-7 (the second wave on each SIMD) run one barrier behind waves 0-3: while one group
     // issues MFMAs the other does its LDS reads and DMA, so the matrix pipe never waits for loads.
     if (wm == 1) MIQ_BARRIER();
 
-    v4i af[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [k-step][fragment]
+    v4i af[2][4] = {}, af2[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [k-step][fragment]
     auto read_w = [&](v4i (&wf)[2][2], const char* half) {
         if (ABL & 2) {   // timing-only build: no LDS reads, operands made opaque
 #pragma unroll
@@ -306,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) wf[ks][j] = lds_read16(half + w_frag + j * 16 * kTileK + lo[ks]);
     };
-    auto read_a = [&](const char* half) {
+    auto read_a = [&](v4i (&af)[2][4], const char* half) {
         if (ABL & 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -319,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[ks][i] = lds_read16(half + a_frag + i * 16 * kTileK + lo[ks]);
     };
-    auto mma = [&](v4i (&c)[4][2], const v4i (&wf)[2][2]) {
+    auto mma = [&](v4i (&c)[4][2], const v4i (&af)[2][4], const v4i (&wf)[2][2]) {
         if (ABL & 16) {   // timing-only build: no MFMAs, operands kept live
             asm volatile("" :: "v"(wf[0][0]), "v"(wf[1][1]), "v"(af[0][0]), "v"(af[1][3]));
             return;
@@ -333,18 +403,89 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
                     c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][j], af[ks][i], c[i][j], 0, 0, 0);
     };
 
+    // Timing-only build (ABL bit 64): cycles between consecutive points of a phase, summed per
+    // phase and segment: [issue reads + DMA | wait DMA | barrier | MFMA issue | barrier].
+    unsigned seg[4][5] = {};
+    unsigned long long last = 0;
+    if constexpr ((ABL & 64) != 0) last = __builtin_amdgcn_s_memtime();
+#define MIQ_STAMP(P, S)                                               \
+    do {                                                              \
+        if constexpr ((ABL & 64) != 0) {                              \
+            const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+            seg[P][S] += static_cast<unsigned>(now - last);           \
+            last = now;                                               \
+        }                                                             \
+    } while (0)
+    if constexpr (VARIANT == 2) read_a(af, smem + 0 * kHalf);   // A0(0)
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * kBuf;
         char* nxt = smem + ((t + 1) & 1) * kBuf;
         if constexpr (VARIANT == 0) {
             // four phases of 16 MFMAs, two barriers each
             read_w(wf0, cur + 2 * kHalf);
-            read_a(cur + 0 * kHalf);
+            read_a(af, cur + 0 * kHalf);
+            stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
+            MIQ_STAMP(0, 0);
+            MIQ_WAIT_DMA();   // W1(t) has landed
+            MIQ_STAMP(0, 1);
+            MIQ_BARRIER();
+            MIQ_STAMP(0, 2);
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][0], af, wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_STAMP(0, 3);
+            MIQ_BARRIER();
+            MIQ_STAMP(0, 4);
+
+            read_w(wf1, cur + 3 * kHalf);
+            stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1);
+            MIQ_STAMP(1, 0);
+            MIQ_WAIT_DMA();   // A1(t)
+            MIQ_STAMP(1, 1);
+            MIQ_BARRIER();
+            MIQ_STAMP(1, 2);
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][1], af, wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_STAMP(1, 3);
+            MIQ_BARRIER();
+            MIQ_STAMP(1, 4);
+
+            read_a(af, cur + 1 * kHalf);
+            stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
+            MIQ_STAMP(2, 0);
+            MIQ_WAIT_DMA();   // A0(t+1)
+            MIQ_STAMP(2, 1);
+            MIQ_BARRIER();
+            MIQ_STAMP(2, 2);
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][1], af, wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_STAMP(2, 3);
+            MIQ_BARRIER();
+            MIQ_STAMP(2, 4);
+
+            stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
+            MIQ_STAMP(3, 0);
+            MIQ_WAIT_DMA();   // W0(t+1)
+            MIQ_STAMP(3, 1);
+            MIQ_BARRIER();
+            MIQ_STAMP(3, 2);
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][0], af, wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_STAMP(3, 3);
+            MIQ_BARRIER();
+            MIQ_STAMP(3, 4);
+        } else if constexpr (VARIANT == 2) {
+            // As variant 0, with the A0 fragments of the next K-tile read one phase early into a
+            // second register set: LDS reads per phase are 4, 4, 8, 8 instead of 12, 4, 8, 0.
+            read_w(wf0, cur + 2 * kHalf);
             stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
             MIQ_WAIT_DMA();   // W1(t) has landed
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
-            mma(acc[0][0], wf0);
+            mma(acc[0][0], af, wf0);
             __builtin_amdgcn_s_setprio(0);
             MIQ_BARRIER();
 
@@ -353,119 +494,37 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             MIQ_WAIT_DMA();   // A1(t)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
-            mma(acc[0][1], wf1);
+            mma(acc[0][1], af, wf1);
             __builtin_amdgcn_s_setprio(0);
             MIQ_BARRIER();
 
-            read_a(cur + 1 * kHalf);
+            read_a(af2, cur + 1 * kHalf);
             stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
             MIQ_WAIT_DMA();   // A0(t+1)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
-            mma(acc[1][1], wf1);
+            mma(acc[1][1], af2, wf1);
             __builtin_amdgcn_s_setprio(0);
             MIQ_BARRIER();
 
+            read_a(af, nxt + 0 * kHalf);   // A0(t+1): retired by the wait one phase ago
             stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
             MIQ_WAIT_DMA();   // W0(t+1)
             MIQ_BARRIER();
             __builtin_amdgcn_s_setprio(1);
-            mma(acc[1][0], wf0);
-            __builtin_amdgcn_s_setprio(0);
-            MIQ_BARRIER();
-        } else {
-            // two phases of 32 MFMAs, two barriers each; LDS reads are drained before the barrier that
-            // ends a load segment, so a half-tile may be restaged one phase after its last read
-            read_w(wf0, cur + 2 * kHalf);
-            read_a(cur + 0 * kHalf);
-            read_w(wf1, cur + 3 * kHalf);
-            stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1);
-            stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            MIQ_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-            mma(acc[0][0], wf0);
-            mma(acc[0][1], wf1);
-            __builtin_amdgcn_s_setprio(0);
-            MIQ_BARRIER();
-
-            read_a(cur + 1 * kHalf);
-            stage_half(ra, cur + 0 * kHalf, abase[0], t + 2);
-            stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            MIQ_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-            mma(acc[1][1], wf1);
-            mma(acc[1][0], wf0);
+            mma(acc[1][0], af2, wf0);
             __builtin_amdgcn_s_setprio(0);
             MIQ_BARRIER();
         }
     }
+    if constexpr ((ABL & 64) != 0) {
+        if (g.stamps != nullptr && lane < 20)
+            g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 20 + lane] = seg[lane / 5][lane % 5];
+    }
     if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
 
-    // Epilogue.  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
-    const bool vec_ok = (g.N & 3) == 0;
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
-            float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (OUT != kOutI32) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) {
-                        al[e] = g.alpha[n + e];
-                        if (g.bias) bi[e] = g.bias[n + e];
-                    }
-            }
-#pragma unroll
-            for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
-                    if (m >= g.M || n >= g.N) continue;
-                    const v4i a = acc[qm][qn][i][j];
-                    const size_t idx = static_cast<size_t>(m) * g.N + n;
-                    if constexpr (OUT == kOutI32) {
-                        int* o = static_cast<int*>(g.out) + idx;
-                        if (vec_ok && n + 3 < g.N) {
-                            *reinterpret_cast<v4i*>(o) = a;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < g.N) o[e] = a[e];
-                        }
-                    } else {
-                        float y[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
-                        if constexpr (OUT == kOutF32) {
-                            float* o = static_cast<float*>(g.out) + idx;
-                            if (vec_ok && n + 3 < g.N) {
-                                *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (n + e < g.N) o[e] = y[e];
-                            }
-                        } else {
-                            uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
-                            if (vec_ok && n + 3 < g.N) {
-                                uint2 p;
-                                p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
-                                p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
-                                *reinterpret_cast<uint2*>(o) = p;
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
-                            }
-                        }
-                    }
-                }
-        }
+    store_tile_256<OUT>(g, acc, m0, n0, wm, wn, lane);
 }
 
 // Any K and any alignment: one thread per output element.  Only shapes the MFMA path cannot
@@ -597,7 +656,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         g.tiles_n = static_cast<int>(ceil_div(g.N, 256));
         constexpr int kLds = 2 * 4 * 128 * kTileK;
         const char* var = getenv("MIQ_GEMM_VARIANT");     // developer A/B switch
-        auto kern = (var && var[0] == '1') ? gemm_i8_256_kernel<OUT, 1> : gemm_i8_256_kernel<OUT, 0>;
+        auto kern = (var && var[0] == '0') ? gemm_i8_256_kernel<OUT, 0> : gemm_i8_256_kernel<OUT, 2>;
         const char* abl = getenv("MIQ_GEMM_ABL");
         if (abl && OUT == kOutF32) {
             if (abl[0] == '1') kern = gemm_i8_256_kernel<OUT, 0, 1>;
@@ -608,6 +667,11 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             if (abl[0] == 'a') kern = gemm_i8_256_kernel<OUT, 0, 32 + 16 + 2>;
             if (abl[0] == 'b') kern = gemm_i8_256_kernel<OUT, 0, 32>;
             if (abl[0] == 'c') kern = gemm_i8_256_kernel<OUT, 0, 32 + 2>;
+            if (abl[0] == 's') {   // segment stamps into the buffer whose address MIQ_GEMM_STAMPS holds (hex)
+                kern = gemm_i8_256_kernel<OUT, 0, 64>;
+                const char* sp = getenv("MIQ_GEMM_STAMPS");
+                g.stamps = sp ? reinterpret_cast<unsigned*>(strtoull(sp, nullptr, 16)) : nullptr;
+            }
             if (abl[0] == '3') kern = gemm_i8_256_kernel<OUT, 0, 3>;
             if (abl[0] == '4') kern = gemm_i8_256_kernel<OUT, 0, 4 + 2>;
             if (abl[0] == '5') kern = gemm_i8_256_kernel<OUT, 0, 8 + 2>;
@@ -692,7 +756,7 @@ extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64
         if (slab_bytes(M, N, K)) slabs = reinterpret_cast<int*>(static_cast<char*>(workspace) + transposed_bytes(w_layout, N, K));
     }
 
-    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0, 0};
+    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0, 0, nullptr};
     // 16-byte vector stores in the epilogue need out rows 16-byte aligned when N % 4 == 0.
     const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
     const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(A, 16) && miq::aligned(W, 16) && out_vec_ok &&
