@@ -572,11 +572,133 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const int* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// M <= 16 (decode): the weight is streamed once, HBM -> MFMA operand registers.  (The kernel is
+// written for MT groups of 16 activation rows, but past one group every wave re-reads MT times its
+// weight bytes of activations from L2 and the tiled kernels with split-K are faster: measured
+// 24 vs 20 us at M = 32 and 33 vs 22 us at M = 64 on [14336, 4096].)
+//
+// Nothing is shared between waves, so there is no LDS staging: a lane loads the 16 bytes the MFMA
+// wants from it (row lane&15 of a 16-row group, chunk lane>>4 of a 64-byte K-step) straight from
+// global memory, for the weight and for the (tiny, L2-resident) activation alike.  A workgroup of
+// 8 waves owns WN*16 output channels; wave s sums the 128-byte K-tiles s, s+8, s+16, ..., so the
+// workgroup reads each of its weight rows as consecutive 1 KiB runs.  Every wave keeps kDepth
+// K-tiles of loads in flight (a ring of register slots: consume one, refill it with the tile
+// kDepth rounds ahead; tiles past K load as zeros and add nothing).  The eight partial sums meet
+// in LDS, and one thread per output finishes the sum and applies the epilogue.
+// ---------------------------------------------------------------------------------------
+template <int MT, int WN, int OUT>
+__global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
+    constexpr int kWaves = 8, kDepth = 4;
+    __shared__ int red[kWaves * MT * WN * 256];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * (WN * 16);
+    const int r = lane & 15, cb = (lane >> 4) * kChunk;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, static_cast<uint32_t>(g.M) * g.K);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+    uint32_t wbase[WN], abase[MT];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + j * 16 + r;
+        wbase[j] = n < g.N ? static_cast<uint32_t>(n) * g.K + cb : kOob;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + r;
+        abase[i] = m < g.M ? static_cast<uint32_t>(m) * g.K + cb : kOob;
+    }
+
+    struct Slot {
+        v4i w[2][WN], a[2][MT];   // [k-step][fragment]
+    };
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t base, int k) -> v4i {
+        const uint32_t off = (base != kOob && k + cb < g.K) ? base + k : kOob;
+        return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    };
+    auto fill = [&](Slot& s, int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k = kt * kTileK + ks * 64;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) s.w[ks][j] = load16(rw, wbase[j], k);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) s.a[ks][i] = load16(ra, abase[i], k);
+        }
+    };
+
+    v4i acc[MT][WN];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    const int nt = (g.K + kTileK - 1) / kTileK;
+    Slot ring[kDepth];
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) fill(ring[u], wave + u * kWaves);
+    for (int t = wave; t < nt; t += kWaves * kDepth) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[u].w[ks][j], ring[u].a[ks][i], acc[i][j], 0, 0, 0);
+            fill(ring[u], t + (u + kDepth) * kWaves);
+        }
+    }
+
+    // D of a fragment: 4*(lane>>4) + reg -> output channel, lane&15 -> activation row.
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            *reinterpret_cast<v4i*>(&red[(((wave * MT + i) * WN + j) * 64 + lane) * 4]) = acc[i][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < MT * 16 * WN * 16; e += 512) {
+        const int ml = e / (WN * 16), nl = e % (WN * 16);
+        const int m = ml, n = n0 + nl;
+        if (m >= g.M || n >= g.N) continue;
+        const int i = ml >> 4, col = ml & 15, j = nl >> 4, ch = nl & 15;
+        const int src = (((i * WN + j) * 64) + (ch >> 2) * 16 + col) * 4 + (ch & 3);
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) sum += red[w * MT * WN * 256 + src];
+        const size_t idx = static_cast<size_t>(m) * g.N + n;
+        if constexpr (OUT == kOutI32) {
+            static_cast<int*>(g.out)[idx] = sum;
+        } else {
+            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
+            if constexpr (OUT == kOutF32) {
+                static_cast<float*>(g.out)[idx] = y;
+            } else {
+                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+            }
+        }
+    }
+}
+
+template <int MT, int OUT>
+int launch_skinny(const GemmArgs& g, hipStream_t st) {
+    // 32 channels per workgroup when that still gives every CU a workgroup, else 16.
+    if (ceil_div(g.N, 32) >= 256) {
+        gemm_i8_skinny_kernel<MT, 2, OUT><<<static_cast<int>(ceil_div(g.N, 32)), 512, 0, st>>>(g);
+    } else {
+        gemm_i8_skinny_kernel<MT, 1, OUT><<<static_cast<int>(ceil_div(g.N, 16)), 512, 0, st>>>(g);
+    }
+    return check_launch("gemm_i8_skinny_kernel");
+}
+
 // Tile and split-K choice for shapes that do not fill the chip with 256 x 256 tiles.  Thin
 // problems (few output tiles, deep K) are cut along K so that a few hundred workgroups stream the
 // weight concurrently; the slices write int32 slabs that splitk_reduce_kernel sums.
 struct GemmPlan {
-    int bm;      // activation rows per tile: 256 (pipelined kernel), 128, 64, 32 or 16
+    int bm;      // activation rows per tile: 256 (pipelined kernel), 128, 64, 32, 16, or 0 = weight-streaming kernel
     int bn;
     int splits;  // 1 = no split
     int kt_per_split;
@@ -586,6 +708,13 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     GemmPlan p{256, 256, 1, 0};
     const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
     if (M > 128 && big_tiles >= 192) return p;
+    if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
+        const char* sk = getenv("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
+        if (!(sk && sk[0] == '0')) {
+            p.bm = 0;
+            return p;
+        }
+    }
     if (M > 64) {
         p.bm = 128; p.bn = 128;
     } else if (M > 32) {
@@ -649,6 +778,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     // Tile choice: the 256x256 tile (8 waves, 128 KiB LDS) once both dimensions can fill the
     // chip with it; smaller tiles keep more workgroups in flight for thin problems.
     const GemmPlan plan = plan_gemm(g.M, g.N, g.K);
+    if (plan.bm == 0) return launch_skinny<1, OUT>(g, st);
     if (plan.bm == 256) {
         const char* simple = getenv("MIQ_GEMM_SIMPLE");   // developer A/B switch
         if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
