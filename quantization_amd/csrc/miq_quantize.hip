@@ -113,6 +113,67 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
            ((static_cast<uint32_t>(c) & 0xffu) << 16) | (static_cast<uint32_t>(d) << 24);
 }
 
+// clamp(rint(x), -128, 127) of four floats as four packed int8.  The clamp goes first (its bounds
+// are integers, so it commutes with the rounding); adding 1.5 * 2^23 then rounds half-to-even and
+// leaves the two's-complement byte in the low 8 bits of the float's bit pattern.
+__device__ __forceinline__ uint32_t round_clamp_pack4(float a, float b, float c, float d) {
+    constexpr float kMagic = 12582912.0f;
+    const uint32_t ua = __float_as_uint(__fadd_rn(__builtin_amdgcn_fmed3f(a, -128.0f, 127.0f), kMagic));
+    const uint32_t ub = __float_as_uint(__fadd_rn(__builtin_amdgcn_fmed3f(b, -128.0f, 127.0f), kMagic));
+    const uint32_t uc = __float_as_uint(__fadd_rn(__builtin_amdgcn_fmed3f(c, -128.0f, 127.0f), kMagic));
+    const uint32_t ud = __float_as_uint(__fadd_rn(__builtin_amdgcn_fmed3f(d, -128.0f, 127.0f), kMagic));
+    const uint32_t lo = __builtin_amdgcn_perm(ub, ua, 0x0c0c0400u);   // a.b0, b.b0, 0, 0
+    const uint32_t hi = __builtin_amdgcn_perm(ud, uc, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// One 16-byte vector of weights -> packed int8, bit-identical to quantize_one on every element.
+//
+// The true division (about a dozen instructions) is replaced by a multiplication with
+// r = fl(1 / s) wherever that provably gives the same int8.  q' = fl(w * r) lies within three units
+// in the last place of the correctly rounded quotient q = fl(w / s) (one rounding each in r, in the
+// product and in q: relative error <= 3 * 2^-24).  The int8 can differ only if a rounding boundary lies between
+// q' and q or on q: a half-integer for fp32 weights, a midpoint of the 16-bit storage format
+// for f16 / bf16 weights (their quotient is rounded to storage before rint).  Lanes whose q' sits
+// within a margin of such a boundary are "unsure"; if any lane of the wave is, the whole vector is
+// redone with the true division (a few per cent of the vectors), otherwise q' is used.
+template <int DT>
+__device__ __forceinline__ typename Vec<DT>::Store quantize_vec(const float (&f)[Vec<DT>::kElems], float s, float r) {
+    using V = Vec<DT>;
+    float qf[V::kElems];
+    bool unsure = false;
+    if constexpr (DT == MIQ_F32) {
+        float margin = 1.0f;   // min over the elements of the distance from q' to the nearest half-integer
+#pragma unroll
+        for (int e = 0; e < V::kElems; ++e) {
+            qf[e] = __fmul_rn(f[e], r);
+            margin = fminf(margin, 0.5f - fabsf(__fsub_rn(qf[e], rintf(qf[e]))));
+        }
+        // |q' - q| < 129 * 2^-22 wherever the clamp does not decide the result anyway
+        unsure = margin < 0x1p-13f;
+    } else {
+        constexpr uint32_t kLowMask = DT == MIQ_BF16 ? 0xffffu : 0x1fffu;   // bits the storage format drops
+        constexpr uint32_t kMid = DT == MIQ_BF16 ? 0x8000u : 0x1000u;
+        uint32_t margin = 0xffffu;
+#pragma unroll
+        for (int e = 0; e < V::kElems; ++e) {
+            const float q = __fmul_rn(f[e], r);
+            margin = min(margin, __usad(__float_as_uint(q) & kLowMask, kMid, 0u));
+            qf[e] = round_to_storage<DT>(q);
+        }
+        unsure = margin <= 4u;   // |q' - q| <= 3 units in the last place of fp32
+    }
+    if (__any(unsure)) {
+#pragma unroll
+        for (int e = 0; e < V::kElems; ++e) qf[e] = round_to_storage<DT>(f[e] / s);
+    }
+    if constexpr (V::kElems == 4) {
+        return round_clamp_pack4(qf[0], qf[1], qf[2], qf[3]);
+    } else {
+        return make_uint2(round_clamp_pack4(qf[0], qf[1], qf[2], qf[3]), round_clamp_pack4(qf[4], qf[5], qf[6], qf[7]));
+    }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -173,21 +234,14 @@ __global__ __launch_bounds__(BLOCK) void quantize_rows_reg_kernel(const uint4* _
             if (row_max) row_max[row] = m;
         }
         typename V::Store* dst = reinterpret_cast<typename V::Store*>(q) + row * nvec;
+        const float rcp_s = 1.0f / s;   // correctly rounded
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int idx = t + j * TPR;
             if (live && idx < nvec) {
                 float f[V::kElems];
                 V::unpack(v[j], f);
-                int r[V::kElems];
-#pragma unroll
-                for (int e = 0; e < V::kElems; ++e) r[e] = quantize_one<DT>(f[e], s);
-                typename V::Store pk;
-                if constexpr (V::kElems == 4) {
-                    pk = pack4(r[0], r[1], r[2], r[3]);
-                } else {
-                    pk = make_uint2(pack4(r[0], r[1], r[2], r[3]), pack4(r[4], r[5], r[6], r[7]));
-                }
+                const typename V::Store pk = quantize_vec<DT>(f, s, rcp_s);
                 if constexpr (NT) {
                     if constexpr (V::kElems == 4) {
                         __builtin_nontemporal_store(pk, &dst[idx]);
@@ -243,17 +297,14 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_stream_kernel(const void
             const int64_t nvec = cols / V::kElems;
             const uint4* src = static_cast<const uint4*>(w) + row * nvec;
             typename V::Store* dst = reinterpret_cast<typename V::Store*>(q) + row * nvec;
-            for (int64_t i = threadIdx.x; i < nvec; i += kBlock) {
-                float f[V::kElems];
-                V::unpack(src[i], f);
-                int r[V::kElems];
-#pragma unroll
-                for (int e = 0; e < V::kElems; ++e) r[e] = quantize_one<DT>(f[e], s);
-                if constexpr (V::kElems == 4) {
-                    dst[i] = pack4(r[0], r[1], r[2], r[3]);
-                } else {
-                    dst[i] = make_uint2(pack4(r[0], r[1], r[2], r[3]), pack4(r[4], r[5], r[6], r[7]));
-                }
+            const float rcp_s = 1.0f / s;   // correctly rounded
+            // Uniform trip count: quantize_vec votes across the wave, so every lane must reach it.
+            const int64_t nvec_up = (nvec + kBlock - 1) / kBlock * kBlock;
+            for (int64_t i = threadIdx.x; i < nvec_up; i += kBlock) {
+                float f[V::kElems] = {};
+                if (i < nvec) V::unpack(src[i], f);
+                const typename V::Store pk = quantize_vec<DT>(f, s, rcp_s);
+                if (i < nvec) dst[i] = pk;
             }
         } else {
             for (int64_t i = threadIdx.x; i < cols; i += kBlock)

@@ -57,6 +57,45 @@ def test_quantizer_full_size(N, rows, cols, std):
     assert int((q[5] != -128).sum()) == 0 and int(q[6].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode", ["normal", "near_ties", "wide"])
+def test_quantizer_every_element_against_true_division(N, dtype, mode):
+    """The kernel multiplies by 1/scale and falls back to the true division only near a rounding
+    boundary.  Every element of a 32M-element matrix against torch's division on the GPU (IEEE,
+    computed in fp32 and rounded to the storage type as on the CPU), including rows built to sit on
+    the boundaries: quotients at and next to half-integers and storage-format midpoints.  A sample
+    of rows is also checked against the CPU oracle, which pins torch's GPU division itself."""
+    rows, cols = 4096, 8192
+    g = torch.Generator(device="cuda").manual_seed(11)
+    if mode == "normal":
+        w = (torch.randn(rows, cols, generator=g, device="cuda") * 0.02).to(dtype)
+    elif mode == "wide":     # many clamped elements, tiny and huge magnitudes in one row
+        w = (torch.randn(rows, cols, generator=g, device="cuda") *
+             torch.logspace(-6, 3, cols, device="cuda")[None, :]).to(dtype)
+    else:
+        # row maximum 127.5 * s makes the scale s; the other elements are (k + 1/2) * s nudged by a few ulps
+        s = (torch.rand(rows, 1, generator=g, device="cuda") + 0.5) * 0.01
+        k = torch.randint(-130, 130, (rows, cols), generator=g, device="cuda").float()
+        nudge = torch.randint(-3, 4, (rows, cols), generator=g, device="cuda").float() * 2.0 ** -22
+        w = ((k + 0.5) * (1.0 + nudge) * s)
+        w[:, 0] = (127.5 * s)[:, 0]
+        w = w.to(dtype)
+    q, scale, zp = N.quantize_rows_sym_i8(w)
+    amax = torch.amax(w, dim=1)
+    # tensor / tensor: torch's GPU division by a Python scalar multiplies by the reciprocal instead
+    ref_scale = torch.maximum(torch.clamp(amax, min=0) / torch.full_like(amax, 127.5),
+                              torch.tensor(2.0 ** -23, device="cuda").to(dtype))
+    assert torch.equal(scale, ref_scale.float()) or torch.equal(scale.to(dtype), ref_scale)
+    ref_q = torch.clamp(torch.round(w / ref_scale[:, None]), -128, 127).to(torch.int8)
+    bad = (q != ref_q)
+    assert not bool(bad.any()), f"{int(bad.sum())} elements differ from the true division"
+    pick = np.random.default_rng(2).choice(rows, 24, replace=False).tolist()
+    kind = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}[dtype]
+    sub = w[pick].float().cpu().numpy() if dtype != torch.float32 else w[pick].cpu().numpy()
+    rq, _, _ = O.quantize_channel_sym_int8(sub, kind=kind)
+    np.testing.assert_array_equal(q[pick].cpu().numpy(), rq)
+
+
 @pytest.mark.parametrize("M,Nn,K", [(4096, 4096, 4096), (8192, 8192, 8192), (256, 14336, 4096), (256, 4096, 14336),
                                      (2048, 28672, 8192), (16, 14336, 4096), (1, 4096, 14336)])
 def test_gemm_full_size_checksums(N, M, Nn, K):
