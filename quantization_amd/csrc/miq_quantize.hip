@@ -21,6 +21,8 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kEps = 1.1920928955078125e-07f;  // 2^-23 = torch.finfo(float32).eps
 constexpr int kBlock = 256;
@@ -152,16 +154,25 @@ __device__ __forceinline__ typename Vec<DT>::Store quantize_vec(const float (&f)
         // |q' - q| < 129 * 2^-22 wherever the clamp does not decide the result anyway
         unsure = margin < 0x1p-13f;
     } else {
-        constexpr uint32_t kLowMask = DT == MIQ_BF16 ? 0xffffu : 0x1fffu;   // bits the storage format drops
-        constexpr uint32_t kMid = DT == MIQ_BF16 ? 0x8000u : 0x1000u;
-        uint32_t margin = 0xffffu;
+        // |q' - q| <= 3 units in the last place of fp32: unsure when the bits the storage format drops
+        // lie within 4 of their midpoint, i.e. (bits - (mid - 4)) mod 2^dropped <= 8.
+        constexpr uint32_t kLowMask = DT == MIQ_BF16 ? 0xffffu : 0x1fffu;
+        constexpr uint32_t kFrom = (DT == MIQ_BF16 ? 0x8000u : 0x1000u) - 4u;
+        uint32_t margin = 0xffffffffu;
 #pragma unroll
-        for (int e = 0; e < V::kElems; ++e) {
-            const float q = __fmul_rn(f[e], r);
-            margin = min(margin, __usad(__float_as_uint(q) & kLowMask, kMid, 0u));
-            qf[e] = round_to_storage<DT>(q);
+        for (int e = 0; e < V::kElems; e += 2) {
+            const float q0 = __fmul_rn(f[e], r), q1 = __fmul_rn(f[e + 1], r);
+            margin = min(margin, min((__float_as_uint(q0) - kFrom) & kLowMask, (__float_as_uint(q1) - kFrom) & kLowMask));
+            if constexpr (DT == MIQ_BF16) {   // one v_cvt_pk_bf16_f32 for the pair
+                const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+                qf[e] = __uint_as_float(u << 16);
+                qf[e + 1] = __uint_as_float(u & 0xffff0000u);
+            } else {
+                qf[e] = round_to_storage<DT>(q0);
+                qf[e + 1] = round_to_storage<DT>(q1);
+            }
         }
-        unsure = margin <= 4u;   // |q' - q| <= 3 units in the last place of fp32
+        unsure = margin <= 8u;
     }
     if (__any(unsure)) {
 #pragma unroll
