@@ -138,13 +138,20 @@ def main():
 
     layer = ColumnShardedLinear(wq, scale, bias_local, n_total, out_dtype=torch.float32)
 
-    def run_steps(n):
+    def run_steps(n, events=None):
         """n forwards of the layer.  The all-gather of step i runs on RCCL's stream while the GEMM of
         step i+1 runs on the compute stream (the steps are independent layers of a stack); at most two
-        gathers are in flight, and every one has completed when this returns."""
+        gathers are in flight, and every one has completed when this returns.  `events` collects a HIP
+        event pair around every GEMM launch, on the stream it is launched on."""
         pending = None
         for _ in range(n):
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             y = layer.local_forward(x)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
             _, work = layer.gather_async(y)
             if pending is not None:
                 pending.wait()
@@ -157,7 +164,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    gemm_events = []
+    run_steps(args.steps, gemm_events)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -167,12 +175,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # --- GEMM kernel alone, HIP events on the launch stream (roofline) -----------------------
-    out = torch.empty(M, S, dtype=torch.float32, device=dev)
-    gemm = lambda: N_.gemm_i8(x, wq, bias=bias_local, alpha=scale, beta=0.0, out=out)  # noqa: E731
-    for _ in range(3):
-        gemm()
-    kt = event_times(gemm, max(10, args.steps))
+    # --- GEMM kernel duration: the event pairs recorded around every launch of the timed region ----
+    kt = [a.elapsed_time(b) for a, b in gemm_events]
     k_ms = sum(kt) / len(kt)
     ops_layer = 2.0 * M * S * K
 
