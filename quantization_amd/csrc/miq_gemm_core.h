@@ -23,6 +23,7 @@ namespace miq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 constexpr int kTileK = 128;                 // bytes (= int8 elements) per K-tile
 constexpr int kChunk = 16;                  // bytes per LDS-DMA piece / MFMA operand per lane
