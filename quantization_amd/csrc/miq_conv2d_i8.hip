@@ -232,6 +232,7 @@ struct ConvArgs {
     int cps;                  // 16-byte chunks per filter row (Lp / 16)
     uint32_t cps_magic;       // floor(2^32 / cps) + 1: q / cps == umulhi(q, cps_magic) for q < 2^16, cps > 1
     uint32_t xp_bytes, wp_bytes;
+    int stream_out;           // 1: nontemporal 16-byte output stores (outputs far larger than the 256 MiB cache)
     int tiles_m, tiles_n;
 };
 
@@ -255,7 +256,7 @@ __device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* ti
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool STREAM>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -368,11 +369,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
                 const int b = m / g.HoWo, p = m % g.HoWo;
                 const size_t idx = (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + p;
                 if constexpr (OUT == kOutI32) {
-                    *reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx) = a;
+                    v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
+                    if constexpr (STREAM) {
+                        __builtin_nontemporal_store(a, o);
+                    } else {
+                        *o = a;
+                    }
                 } else if constexpr (OUT == kOutF32) {
-                    *reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx) =
-                        v4f{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
-                            dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta)};
+                    const v4f y{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta)};
+                    v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
+                    if constexpr (STREAM) {
+                        __builtin_nontemporal_store(y, o);
+                    } else {
+                        *o = y;
+                    }
                 } else {
                     uint2 pk;
                     pk.x = f32_to_bf16_bits(dequant1(a[0], bi, al, g.beta)) |
@@ -403,10 +414,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tile(ConvArgs g, hipStream_t st) {
+    constexpr bool kCanStream = OUT != kOutBF16;   // 8-byte nontemporal stores are slower than cached ones
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
     const int lds = 2 * (BM + BN) * kTileK;
-    auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
+    auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false>;
+    if constexpr (kCanStream) {
+        if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
+    }
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
     return check_launch("conv_i8_kernel");
@@ -558,6 +573,10 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
     a.cps_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(a.cps)) + 1u;
     a.xp_bytes = static_cast<uint32_t>(G.xp_bytes);
     a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
+    // Measured at batch 256 with the output rotating over three buffers: nontemporal stores gain 14 % on the
+    // 822 MB output of ResNet-18's first layer and 3 % at 205 MB, and lose 8-40 % on outputs of 26-103 MB,
+    // which the Infinity Cache absorbs.
+    a.stream_out = G.M * Cout * 4 >= (192ll << 20);
     switch (out_dtype) {
         case MIQ_F32:
             return launch<kOutF32>(a, st);

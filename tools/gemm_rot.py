@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""8192^3 GEMM with the output rotating over several buffers (as a stack of layers writes it), A/B of
-developer switches in one process:  python tools/gemm_rot.py ROUNDS LAUNCHES SPEC [SPEC ...]
+"""SIZE^3 GEMM with the output rotating over several buffers (as a stack of layers writes it), A/B of
+developer switches in one process:  python tools/gemm_rot.py SIZE ROUNDS LAUNCHES SPEC [SPEC ...]
 SPEC = VARIANT[,ABL] as in tools/gemm_ab.py."""
 import os
 import statistics
@@ -12,8 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization_amd import _native as N  # noqa: E402
 from tools.gemm_ab import set_variant  # noqa: E402
 
-rounds, launches, specs = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3:]
-S = 8192
+S, rounds, launches, specs = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4:]
 g = torch.Generator(device="cuda").manual_seed(0)
 a = torch.randint(-128, 128, (S, S), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
 w = torch.randint(-128, 128, (S, S), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)

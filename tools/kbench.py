@@ -84,8 +84,12 @@ def bench_conv():
         alpha = torch.rand(Co, device="cuda") * 0.01
         Ho = (H + 2 * p - k) // s + 1
         for od in (torch.int32, torch.bfloat16):
-            out = torch.empty(B, Co, Ho, Ho, dtype=od, device="cuda")
-            fn = lambda: N.conv2d_i8(x, w, s, p, alpha=alpha, out_dtype=od, out=out)  # noqa: E731
+            outs = [torch.empty(B, Co, Ho, Ho, dtype=od, device="cuda") for _ in range(3)]   # rotate, as a network does
+            cnt = [0]
+
+            def fn():
+                cnt[0] += 1
+                N.conv2d_i8(x, w, s, p, alpha=alpha, out_dtype=od, out=outs[cnt[0] % 3])
             med, mn = timeit(fn, iters=10, warmup=3)
             ops = 2.0 * B * Co * Ho * Ho * C * k * k
             print(f"conv B={B} {C}->{Co} {H}x{H} k{k}s{s}p{p} out={str(od)[6:]}: med {med*1e3:.1f} us  {ops/med/1e9:.0f} TOPS", flush=True)
