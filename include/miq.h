@@ -147,6 +147,23 @@ int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int6
                   const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* 2-D pooling with an int8 result, NCHW: what QuantizedMaxPool2d / QuantizedAvgPool2d compute
+ * (quant/Weight_Activation/Quantizer.py:122-130: nn.MaxPool2d / nn.AvgPool2d on x.float(), then
+ * .to(torch.int8)), in one pass over x.
+ *
+ * x_dtype: MIQ_F32, MIQ_F16, MIQ_BF16 or MIQ_I8.  mode MIQ_POOL_MAX: maximum over the window,
+ * padding never wins.  mode MIQ_POOL_AVG: fp32 sum over the window in row-major order divided by
+ * kh*kw (padding counts as zeros: count_include_pad=True, the module's default).  Output size
+ * (H + 2*ph - kh)/sh + 1 (ceil_mode=False), dilation 1: the arguments the reference's Chunker
+ * forwards (quant/Weight_Activation/Chunker.py:75-77).  The cast to int8 truncates toward zero
+ * and wraps modulo 256 as the host's cast does (200.0 -> -56); NaN and |v| >= 2^31 give 0.
+ */
+#define MIQ_I8 4 /* inputs only */
+#define MIQ_POOL_MAX 0
+#define MIQ_POOL_AVG 1
+int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw,
+                     int sh, int sw, int ph, int pw, int mode, int8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,9 +205,52 @@ def config1_models(mods):
     return out
 
 
+POOL_CASES = [
+    # name, mode, x dtype, shape, kernel, stride, padding, value scale
+    ("max_k2", "max", "f32", (2, 3, 8, 8), 2, 2, 0, 60.0),
+    ("max_k3s2p1", "max", "f32", (2, 4, 9, 11), 3, 2, 1, 200.0),      # values past int8: the cast wraps
+    ("max_rect", "max", "f32", (1, 2, 10, 13), (2, 3), (2, 1), (1, 1), 50.0),
+    ("avg_k2", "avg", "f32", (2, 3, 8, 8), 2, 2, 0, 60.0),
+    ("avg_k3s1p1", "avg", "f32", (1, 2, 7, 10), 3, 1, 1, 100.0),      # padding counts in the divisor
+    ("avg_rect", "avg", "f32", (2, 2, 9, 12), (3, 2), (1, 2), (1, 0), 300.0),
+    ("max_i8", "max", "i8", (2, 3, 12, 12), 2, 2, 0, 0.0),
+    ("avg_i8", "avg", "i8", (2, 3, 11, 14), 3, 2, 1, 0.0),
+    ("max_f16", "max", "f16", (1, 3, 8, 16), 2, 2, 0, 40.0),
+    ("avg_bf16", "avg", "bf16", (1, 3, 8, 16), 2, 2, 0, 40.0),
+]
+
+
+def pool_input(name, kind, shape, scale):
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    if kind == "i8":
+        return torch.randint(-128, 128, shape, generator=g, dtype=torch.int32).to(torch.int8)
+    x = torch.randn(shape, generator=g) * scale
+    return x.to({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[kind])
+
+
+def pool_cases(mods):
+    """QuantizedMaxPool2d / QuantizedAvgPool2d (quant/Weight_Activation/Quantizer.py:122-130), constructed with
+    the arguments the Chunker forwards (kernel_size, stride, padding: Chunker.py:75-77)."""
+    Q = mods["Quantizer"]
+    out = {}
+    for name, mode, kind, shape, k, s, p, scale in POOL_CASES:
+        x = pool_input(name, kind, shape, scale)
+        cls = Q.QuantizedMaxPool2d if mode == "max" else Q.QuantizedAvgPool2d
+        y = cls(kernel_size=k, stride=s, padding=p)(x)
+        assert y.dtype == torch.int8
+        out[name + "/x"] = x.numpy() if kind == "i8" else as_f32(x)
+        out[name + "/y"] = y.numpy()
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["pools"]:
+        wa = load_ref("Weight_Activation")
+        np.savez_compressed(os.path.join(OUT, "pools.npz"), **pool_cases(wa))
+        print("pools.npz", os.path.getsize(os.path.join(OUT, "pools.npz")))
+        return
     wo = load_ref("Weight_Only")
     np.savez_compressed(os.path.join(OUT, "quantizer_wo.npz"), **quantizer_cases(wo["Qop"].Qop))
     np.savez_compressed(os.path.join(OUT, "wo_forward.npz"), **wo_forward_cases(wo))
@@ -215,6 +258,7 @@ def main():
     wa = load_ref("Weight_Activation")
     np.savez_compressed(os.path.join(OUT, "quantizer_wa.npz"), **quantizer_cases(wa["Qop"].Qop, full=False))
     np.savez_compressed(os.path.join(OUT, "wa_chunker.npz"), **wa_chunker_case(wa))
+    np.savez_compressed(os.path.join(OUT, "pools.npz"), **pool_cases(wa))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -220,3 +220,49 @@ def shard_rows(n, world, rank):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def cast_f32_to_int8(v):
+    """float32 -> int8 as torch's CPU `.to(torch.int8)` does (the C cast chain float -> int32 ->
+    int8): truncate toward zero, keep the low byte (200.0 -> -56); NaN and |v| >= 2^31 -> 0."""
+    v = np.asarray(v, dtype=np.float32)
+    ok = np.abs(v) < np.float32(2147483648.0)          # False for NaN
+    i32 = np.where(ok, v, np.float32(0)).astype(np.int32)
+    return (i32 & 0xFF).astype(np.uint8).view(np.int8)
+
+
+def pool2d_to_int8(x, kernel_size, stride=None, padding=0, mode="max"):
+    """QuantizedMaxPool2d / QuantizedAvgPool2d.forward (quant/Weight_Activation/Quantizer.py:122-130):
+    nn.MaxPool2d / nn.AvgPool2d on x.float() with the module defaults (dilation 1, ceil_mode False,
+    count_include_pad True), then .to(torch.int8).  x: [B, C, H, W], any real dtype (values are
+    taken as float32).  The average is a float32 running sum over the window in row-major order
+    divided by kh*kw, as torch's CPU kernel computes it."""
+    def pair(v):
+        return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
+    kh, kw = pair(kernel_size)
+    sh, sw = pair(kernel_size if stride is None else stride)
+    ph, pw = pair(padding)
+    xf = np.asarray(x).astype(np.float32)
+    B, C, H, W = xf.shape
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    res = np.full((B, C, Ho, Wo), -np.inf if mode == "max" else 0.0, dtype=np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            # output (ho, wo) reads input (ho*sh - ph + i, wo*sw - pw + j) when that lies inside x
+            ho_lo = max(0, -((i - ph) // sh)) if i < ph else 0
+            wo_lo = max(0, -((j - pw) // sw)) if j < pw else 0
+            ho_hi = min(Ho, (H - 1 + ph - i) // sh + 1)
+            wo_hi = min(Wo, (W - 1 + pw - j) // sw + 1)
+            if ho_hi <= ho_lo or wo_hi <= wo_lo:
+                continue
+            hs = slice(ho_lo * sh - ph + i, (ho_hi - 1) * sh - ph + i + 1, sh)
+            ws = slice(wo_lo * sw - pw + j, (wo_hi - 1) * sw - pw + j + 1, sw)
+            v = xf[:, :, hs, ws]
+            dst = res[:, :, ho_lo:ho_hi, wo_lo:wo_hi]
+            if mode == "max":
+                np.copyto(dst, np.where((v > dst) | np.isnan(v), v, dst))
+            else:
+                np.copyto(dst, (dst + v).astype(np.float32))   # one fp32 rounding per term, row-major order
+    if mode != "max":
+        res = (res / np.float32(kh * kw)).astype(np.float32)
+    return cast_f32_to_int8(res)

@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmiq.so")
 
-MIQ_F32, MIQ_F16, MIQ_BF16, MIQ_I32 = 0, 1, 2, 3
+MIQ_F32, MIQ_F16, MIQ_BF16, MIQ_I32, MIQ_I8 = 0, 1, 2, 3, 4
+MIQ_POOL_MAX, MIQ_POOL_AVG = 0, 1
 MIQ_W_NK, MIQ_W_KN = 0, 1
 
 _FLOAT_CODES = {torch.float32: MIQ_F32, torch.float16: MIQ_F16, torch.bfloat16: MIQ_BF16}
@@ -39,6 +40,7 @@ SYMBOLS = {
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_pool2d_to_i8": (_int, [_p, _int] + [_i64] * 4 + [_int] * 7 + [_p, _p]),
 }
 
 _lib = None
@@ -176,6 +178,31 @@ def transpose_i8(src):
     with torch.cuda.device(src.device):
         _check(lib().miq_transpose_i8(_ptr(src), rows, cols, _ptr(dst), _stream()))
     return dst
+
+
+def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):
+    """Max / average pooling of x [B, C, H, W] (float or int8) with an int8 result, as the reference's
+    QuantizedMaxPool2d / QuantizedAvgPool2d (pool x.float(), then .to(torch.int8))."""
+    require_device(x, "input")
+    if x.dim() != 4:
+        raise RuntimeError(f"input must be [B, C, H, W] (got {tuple(x.shape)})")
+    code = MIQ_I8 if x.dtype == torch.int8 else _FLOAT_CODES.get(x.dtype)
+    if code is None:
+        raise RuntimeError(f"input must be float32, float16, bfloat16 or int8 (got {x.dtype})")
+
+    def pair(v):
+        return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+    kh, kw = pair(kernel_size)
+    sh, sw = pair(kernel_size if stride is None else stride)
+    ph, pw = pair(padding)
+    B, C, H, W = x.shape
+    if H + 2 * ph < kh or W + 2 * pw < kw:
+        raise RuntimeError("pooling window larger than the padded input")
+    out = torch.empty((B, C, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1), dtype=torch.int8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().miq_pool2d_to_i8(_ptr(x), code, B, C, H, W, kh, kw, sh, sw, ph, pw,
+                                      MIQ_POOL_MAX if mode == "max" else MIQ_POOL_AVG, _ptr(out), _stream()))
+    return out
 
 
 def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):

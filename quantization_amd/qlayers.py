@@ -265,18 +265,32 @@ class WeightActivationQuantizer(_QuantizerBase):
         return self._repr(self._weight_details())
 
 
+def _pool_to_i8(module, x, mode):
+    """One fused kernel for `pool(x.float()).to(torch.int8)`.  The reference builds these modules with
+    kernel_size, stride and padding only (Chunker.py:75-77); other settings are not implemented."""
+    if getattr(module, "ceil_mode", False) or getattr(module, "dilation", 1) not in (1, (1, 1)) \
+            or getattr(module, "return_indices", False) or not getattr(module, "count_include_pad", True) \
+            or getattr(module, "divisor_override", None) is not None:
+        raise NotImplementedError("int8 pooling supports kernel_size, stride and padding only")
+    if x.dim() == 3:
+        return _pool_to_i8(module, x.unsqueeze(0), mode).squeeze(0)
+    home = x.device
+    xd = _to_gpu(x).contiguous()
+    return _native.pool2d_to_i8(xd, module.kernel_size, module.stride, module.padding, mode).to(home)
+
+
 class QuantizedMaxPool2d(nn.MaxPool2d):
     """quant/Weight_Activation/Quantizer.py:122-125."""
 
     def forward(self, x):
-        return super().forward(x.float()).to(torch.int8)
+        return _pool_to_i8(self, x, "max")
 
 
 class QuantizedAvgPool2d(nn.AvgPool2d):
     """quant/Weight_Activation/Quantizer.py:127-130."""
 
     def forward(self, x):
-        return super().forward(x.float()).to(torch.int8)
+        return _pool_to_i8(self, x, "avg")
 
 
 class WeightActivationChunker:

@@ -134,3 +134,21 @@ def test_conv_resnet18_batch256(N, C, H, Co, k, s, p):
     for b in (0, 137, 255):
         ref = torch.nn.functional.conv2d(x[b:b + 1].double(), w.double(), stride=s, padding=p).to(torch.int32)
         assert torch.equal(out[b:b + 1], ref)
+
+
+@pytest.mark.parametrize("mode,dtype,shape,k,s,p", [("max", torch.int8, (256, 64, 112, 112), 3, 2, 1),
+                                                     ("max", torch.float32, (256, 64, 112, 112), 3, 2, 1),
+                                                     ("avg", torch.int8, (256, 512, 7, 7), 7, 1, 0),
+                                                     ("avg", torch.float32, (64, 128, 56, 56), 2, 2, 0)])
+def test_pool_resnet_sizes(N, mode, dtype, shape, k, s, p):
+    """ResNet-18's pooling layers at batch 256 against torch's pooling of x.float() on the GPU (int8-valued
+    inputs: max is exact and every partial sum of the average is an integer below 2^24, so any summation
+    order gives the same float) followed by the truncating cast; sampled planes against the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randint(-128, 128, shape, generator=g, dtype=torch.int32, device="cuda").to(dtype)
+    y = N.pool2d_to_i8(x, k, s, p, mode)
+    f = torch.nn.functional
+    ref = f.max_pool2d(x.float(), k, s, p) if mode == "max" else f.avg_pool2d(x.float(), k, s, p)
+    assert torch.equal(y, ref.to(torch.int8))
+    sub = x[3:5, 7:9].cpu().numpy()
+    np.testing.assert_array_equal(y[3:5, 7:9].cpu().numpy(), O.pool2d_to_int8(sub, k, s, p, mode))

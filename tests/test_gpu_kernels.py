@@ -302,3 +302,67 @@ def test_wa_epilogue_golden(N):
             y = N.gemm_i8(x, wq, bias=bias, alpha=scalers, beta=ozp)
         ref = WA.get(name, "y")
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+# ---- int8 pooling (QuantizedMaxPool2d / QuantizedAvgPool2d) ------------------------------------
+def _pool_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "pools.npz"))
+
+
+@pytest.mark.gpu
+def test_pool_matches_reference_fixture():
+    from oracle.gen_golden import POOL_CASES
+    from quantization_amd import _native as N
+    fix = _pool_fixture()
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i8": torch.int8}
+    for name, mode, kind, shape, k, s, p, _ in POOL_CASES:
+        x = torch.from_numpy(fix[name + "/x"]).to(tdt[kind]).cuda()
+        y = N.pool2d_to_i8(x, k, s, p, mode)
+        np.testing.assert_array_equal(y.cpu().numpy(), fix[name + "/y"], err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["max", "avg"])
+@pytest.mark.parametrize("shape,k,s,p", [((3, 5, 17, 19), 3, 2, 1), ((2, 4, 16, 16), 2, 2, 0), ((1, 1, 5, 3), (2, 3), (1, 1), (1, 1)),
+                                          ((2, 3, 9, 33), (3, 2), (2, 3), (0, 1)), ((1, 7, 1, 1), 1, 1, 0), ((0, 4, 8, 8), 2, 2, 0),
+                                          ((2, 3, 32, 48), 3, 2, 1), ((2, 3, 10, 64), 3, 1, 1), ((1, 5, 64, 32), 2, 2, 0), ((1, 2, 9, 40), 3, 2, 1)])
+@pytest.mark.parametrize("kind", ["f32", "i8", "bf16"])
+def test_pool_against_oracle(mode, shape, k, s, p, kind):
+    from quantization_amd import _native as N
+    g = torch.Generator().manual_seed(5)
+    if kind == "i8":
+        x = torch.randint(-128, 128, shape, generator=g, dtype=torch.int32).to(torch.int8)
+    else:
+        x = (torch.randn(shape, generator=g) * 90).to(torch.float32 if kind == "f32" else torch.bfloat16)
+    y = N.pool2d_to_i8(x.cuda(), k, s, p, mode)
+    ref = O.pool2d_to_int8(x.float().numpy() if kind != "i8" else x.numpy(), k, s, p, mode)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_pool_layers_drop_in():
+    """The layer classes the weight+activation Chunker installs, on CPU and GPU tensors."""
+    from quantization_amd.quant.Weight_Activation.Quantizer import QuantizedAvgPool2d, QuantizedMaxPool2d
+    x = torch.randn(2, 3, 8, 8) * 50
+    for cls, mode in ((QuantizedMaxPool2d, "max"), (QuantizedAvgPool2d, "avg")):
+        m = cls(kernel_size=2, stride=2, padding=0)
+        ref = O.pool2d_to_int8(x.numpy(), 2, 2, 0, mode)
+        y = m(x)
+        assert y.dtype == torch.int8 and y.device.type == "cpu"
+        np.testing.assert_array_equal(y.numpy(), ref)
+        np.testing.assert_array_equal(m(x.cuda()).cpu().numpy(), ref)
+    with pytest.raises(NotImplementedError):
+        QuantizedMaxPool2d(kernel_size=2, ceil_mode=True)(x)
+
+
+@pytest.mark.gpu
+def test_pool_rejects_bad_arguments():
+    from quantization_amd import _native as N
+    x = torch.zeros(1, 1, 4, 4, device="cuda")
+    with pytest.raises(RuntimeError, match="pad must be at most half"):
+        N.pool2d_to_i8(x, 2, 2, 2, "max")
+    with pytest.raises(RuntimeError, match="window larger"):
+        N.pool2d_to_i8(x, 7, 1, 0, "max")
+    with pytest.raises(RuntimeError, match="must be float32"):
+        N.pool2d_to_i8(x.double(), 2, 2, 0, "max")

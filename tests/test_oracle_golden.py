@@ -2,6 +2,8 @@
 reference's own Python (oracle/gen_golden.py); the oracle must reproduce each bit for bit
 (int8 / int64 / scales) or to 1e-6 relative (fp32 layer outputs, where the reference ran a
 float GEMM on integer-valued inputs and the oracle an exact integer one)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -152,3 +154,19 @@ def test_torch_baseline_port_matches_reference():
             stride, pad = (int(v) for v in FW.get(case, "stride_pad"))
             y = T.wo_conv2d_forward(x, q, s, zp, b, stride, pad)
         np.testing.assert_array_equal(y.numpy(), FW.get(case, "y"))
+
+
+def test_pool_oracle_matches_reference_fixture():
+    """oracle_np.pool2d_to_int8 against QuantizedMaxPool2d / QuantizedAvgPool2d outputs generated by
+    the reference (tests/golden/pools.npz; oracle/gen_golden.py::pool_cases)."""
+    from oracle.gen_golden import POOL_CASES
+    fix = np.load(os.path.join(os.path.dirname(__file__), "golden", "pools.npz"))
+    for name, mode, kind, shape, k, s, p, _ in POOL_CASES:
+        y = O.pool2d_to_int8(fix[name + "/x"], k, s, p, mode)
+        assert y.dtype == np.int8
+        np.testing.assert_array_equal(y, fix[name + "/y"], err_msg=name)
+
+
+def test_cast_to_int8_wraps_like_the_host_cast():
+    v = np.array([1.9, -1.9, 127.9, 128.0, 200.0, 300.5, -129.7, -300.2, 1e10, -1e10, np.nan, np.inf], dtype=np.float32)
+    np.testing.assert_array_equal(O.cast_f32_to_int8(v), np.array([1, -1, 127, -128, -56, 44, 127, -44, 0, 0, 0, 0], np.int8))

@@ -95,8 +95,18 @@ def bench_conv():
             print(f"conv B={B} {C}->{Co} {H}x{H} k{k}s{s}p{p} out={str(od)[6:]}: med {med*1e3:.1f} us  {ops/med/1e9:.0f} TOPS", flush=True)
 
 
+def bench_pool():
+    for mode, dt, shape, k, st, p in (("max", torch.int8, (256, 64, 112, 112), 3, 2, 1), ("max", torch.float32, (256, 64, 112, 112), 3, 2, 1),
+                                      ("avg", torch.float32, (256, 128, 56, 56), 2, 2, 0), ("avg", torch.int8, (256, 512, 7, 7), 7, 1, 0)):
+        x = torch.randint(-128, 128, shape, dtype=torch.int32, device="cuda").to(dt)
+        y = N.pool2d_to_i8(x, k, st, p, mode)
+        med, mn = timeit(lambda: N.pool2d_to_i8(x, k, st, p, mode))
+        nbytes = x.numel() * x.element_size() + y.numel()
+        print(f"pool {mode} {str(dt)[6:]} {shape} k{k}s{st}p{p}: med {med*1e3:.1f} us  {nbytes/med/1e6:.0f} GB/s (in + out bytes)", flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quant", "gemm", "conv", "small"]
+    which = sys.argv[1:] or ["quant", "gemm", "conv", "small", "pool"]
     t0 = time.time()
     if "quant" in which:
         bench_quant()
@@ -106,4 +116,6 @@ if __name__ == "__main__":
         bench_small()
     if "conv" in which:
         bench_conv()
+    if "pool" in which:
+        bench_pool()
     print(f"done in {time.time()-t0:.1f}s")
