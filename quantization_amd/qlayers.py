@@ -57,6 +57,36 @@ class _QuantizerBase(nn.Module):
         self._wfloat = None
         return self
 
+    # ---- persisted quantization parameters ------------------------------------------------
+    # The reference's state_dict carries the int8 `weight` buffer only: its scales live on a plain
+    # Python Qop (Weight_Only/Quantizer.py:34,49) or on plain attributes (Weight_Activation/
+    # Quantizer.py:97) and are lost on save.  Here they travel as the module's extra state, under
+    # `<name>._extra_state`, next to the same `weight` key, so a saved quantized model reloads
+    # without re-quantizing.  A state_dict without that key (one the reference wrote) still loads.
+    def _quant_state(self):
+        raise NotImplementedError
+
+    def _set_quant_state(self, state):
+        raise NotImplementedError
+
+    def get_extra_state(self):
+        def cpu(v):
+            return v.detach().to("cpu").clone() if isinstance(v, torch.Tensor) else v
+        return {k: cpu(v) for k, v in self._quant_state().items()}
+
+    def set_extra_state(self, state):
+        dev = self.weight.device
+        self._set_quant_state({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in state.items()})
+        self._wfloat = None
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        key = prefix + "_extra_state"
+        if key in missing_keys:
+            missing_keys.remove(key)
+
     # ---- the two products -------------------------------------------------------------
     def _int8_product(self, x, bias, alpha, beta):
         w = _to_gpu(self.weight)
@@ -161,6 +191,12 @@ class WeightOnlyQuantizer(_QuantizerBase):
             wq.scales = wq.scales.view([1, wq.scales.shape[0], *wq.scales.shape[2:]])
         return y
 
+    def _quant_state(self):
+        return {"scales": self.weight_quant.scales, "zero_point": self.weight_quant.zero_point}
+
+    def _set_quant_state(self, state):
+        self.weight_quant.scales, self.weight_quant.zero_point = state["scales"], state["zero_point"]
+
     @classmethod
     def from_float(cls, module, quantize_output=False, activations=None, data_metry=None):
         new_module = cls(bias=module.bias, quantize_output=quantize_output, data_metrics=data_metry,
@@ -242,6 +278,15 @@ class WeightActivationQuantizer(_QuantizerBase):
         ozp = self.output_zero_point
         beta = float(ozp.reshape(-1)[0]) if isinstance(ozp, torch.Tensor) else float(ozp)
         return self._run(x, bias, self.scalers, beta)
+
+    _STATE = ("bias", "weight_qscale", "weight_zero_point", "scalers", "output_zero_point")
+
+    def _quant_state(self):
+        return {k: getattr(self, k) for k in self._STATE}
+
+    def _set_quant_state(self, state):
+        for k in self._STATE:
+            setattr(self, k, state[k])
 
     @classmethod
     def from_float(cls, module, quantize_output=False, activations=None, data_metry=None):

@@ -239,3 +239,59 @@ def test_conv2d_int8_reference_script():
     conv2d_int8.conv2d_int8(x, k, out2, 2, 1)            # the stride is honoured (F.conv2d semantics)
     ref2 = torch.nn.functional.conv2d(x.float(), k.float(), stride=2, padding=1)
     assert torch.equal(out2, ref2.to(torch.int32))
+
+
+# ---- persisted quantization parameters ------------------------------------------------------------
+@pytest.mark.gpu
+def test_quantized_state_dict_round_trip_weight_only(tmp_path):
+    """state_dict of a weight-only quantized model carries the scales (as each layer's extra state), survives
+    torch.save / torch.load(weights_only=True), and a freshly built model that loads it reproduces the
+    outputs bit for bit; a state_dict without the extra state (what the reference writes) still loads."""
+    import io
+    from quantization_amd.quant.Weight_Only.Chunker import Chunker
+    from sample_models import SimpleCNN
+    torch.manual_seed(0)
+    m1 = SimpleCNN().eval()
+    Chunker(m1, None)
+    sd = m1.state_dict()
+    assert any(k.endswith("_extra_state") for k in sd)
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    sd2 = torch.load(buf, weights_only=True)
+    torch.manual_seed(123)                       # different float weights: everything must come from the file
+    m2 = SimpleCNN().eval()
+    Chunker(m2, None)
+    m2.load_state_dict(sd2)
+    x = torch.rand(4, 3, 32, 32)
+    assert torch.equal(m1(x), m2(x))
+    for (n1, a), (n2, b) in zip(m1.named_modules(), m2.named_modules()):
+        if hasattr(a, "weight_quant"):
+            assert torch.equal(a.weight, b.weight)
+            assert torch.equal(a.weight_quant.scales.reshape(-1).cpu(), b.weight_quant.scales.reshape(-1).cpu())
+    legacy = {k: v for k, v in sd2.items() if not k.endswith("_extra_state")}
+    m2.load_state_dict(legacy)                   # strict: the missing extra state is tolerated
+
+
+@pytest.mark.gpu
+def test_quantized_state_dict_round_trip_weight_activation():
+    import io
+    from quantization_amd.quant.Weight_Activation.Chunker import Chunker
+    from sample_models import SimpleCNN
+
+    def calib(seed):
+        g = torch.Generator().manual_seed(seed)
+        return [(torch.rand(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(2)]
+    torch.manual_seed(0)
+    m1 = SimpleCNN().eval()
+    Chunker(m1, calib(1))
+    buf = io.BytesIO()
+    torch.save(m1.state_dict(), buf)
+    buf.seek(0)
+    torch.manual_seed(5)
+    m2 = SimpleCNN().eval()
+    Chunker(m2, calib(2))
+    m2.load_state_dict(torch.load(buf, weights_only=True))
+    x = torch.rand(4, 3, 32, 32)
+    y1, y2 = m1(x), m2(x)
+    assert y1.dtype == y2.dtype and torch.equal(y1, y2)
