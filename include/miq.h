@@ -164,6 +164,32 @@ int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int6
 int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw,
                      int sh, int sw, int ph, int pw, int mode, int8_t* out, void* stream);
 
+/* min_max[0] = min(x), min_max[1] = max(x) over all n elements of x (fp32 results, on the device).
+ *
+ * The reduction of the per-tensor branch of Qop.compute_scales_zero_point
+ * (quant/Weight_Only/Qop.py:97-99: tensor.max(), tensor.min()), the form the reference configures
+ * its activation quantizer with (quant/Weight_Only/Quantizer.py:38-43).  One read of x.  The
+ * scale / zero point follow on the host from Qop.calculate_params (Qop.py:62-65) and the int8
+ * tensor from miq_quantize_rows_given_i8 with per_row = 0.
+ * workspace: at least miq_tensor_minmax_workspace(n) bytes (a few KiB of partial results).
+ */
+size_t miq_tensor_minmax_workspace(int64_t n);
+int miq_tensor_minmax(const void* x, int x_dtype, int64_t n, float* min_max, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* From min_max (as miq_tensor_minmax leaves it), on the device and in one launch:
+ *   scale_zp[0] = max((max(max,0) - min(min,0)) / 255, 2^-23)            Qop.calculate_params, per-tensor
+ *   scale_zp[1] = clamp(trunc(-128 - rint(min(min,0) / scale)), -128, 127)  affine branch (Qop.py:40-41, 62-65)
+ * and, for a weight-only layer (quant/Weight_Only/Quantizer.py:79-86) evaluated on the activation
+ * x_hat = scale * (q - zero_point) that miq_quantize_rows_given_i8(x, scale_zp, scale_zp + 1, per_row = 0)
+ * produces, the per-channel vectors its int8 product needs as miq_gemm_i8's `alpha` and `bias`:
+ *   alpha[n] = w_scale[n] * scale
+ *   corr[n]  = bias[n] / scale - zero_point * w_rowsum[n]        (bias may be NULL)
+ * w_rowsum[n] = sum_k Wq[n,k] as fp32.  No counterpart runs in the reference: its activation quantizer is
+ * configured (Quantizer.py:38-44) but its call sites are commented out (Quantizer.py:69-70). */
+int miq_dynamic_epilogue_i8(const float* min_max, const float* w_scale, const float* bias, const float* w_rowsum,
+                            int64_t n, float* scale_zp, float* alpha, float* corr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,3 +266,15 @@ def pool2d_to_int8(x, kernel_size, stride=None, padding=0, mode="max"):
     if mode != "max":
         res = (res / np.float32(kh * kw)).astype(np.float32)
     return cast_f32_to_int8(res)
+
+
+def quantize_tensor_affine_int8(x):
+    """Per-tensor asymmetric int8 quantization with the reference's formulas: min / max over the whole
+    tensor (quant/Weight_Only/Qop.py:97-99), calculate_params' per-tensor affine branch (Qop.py:62-65),
+    q = round(x / scale + zero_point).clamp(-128, 127) (Qop.py:157), all in float32.
+    Returns (q int8, scale [1] float32, zero_point [1] int32)."""
+    x = np.asarray(x, dtype=np.float32)
+    scale, zp = calculate_params_affine_tensor(x.min(), x.max())
+    v = (x / scale[0]).astype(np.float32) + np.float32(zp[0])
+    q = np.clip(np.rint(v.astype(np.float32)), INT8_MIN, INT8_MAX).astype(np.int8)
+    return q, scale, zp

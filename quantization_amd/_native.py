@@ -41,6 +41,9 @@ SYMBOLS = {
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_pool2d_to_i8": (_int, [_p, _int] + [_i64] * 4 + [_int] * 7 + [_p, _p]),
+    "miq_tensor_minmax_workspace": (_size, [_i64]),
+    "miq_tensor_minmax": (_int, [_p, _int, _i64, _p, _p, _size, _p]),
+    "miq_dynamic_epilogue_i8": (_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
 }
 
 _lib = None
@@ -178,6 +181,37 @@ def transpose_i8(src):
     with torch.cuda.device(src.device):
         _check(lib().miq_transpose_i8(_ptr(src), rows, cols, _ptr(dst), _stream()))
     return dst
+
+
+def tensor_minmax(x):
+    """[min(x), max(x)] as a 2-element fp32 tensor on x's device (no host synchronisation)."""
+    require_device(x, "tensor")
+    if x.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"tensor must be float32, float16 or bfloat16 (got {x.dtype})")
+    n = x.numel()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    need = lib().miq_tensor_minmax_workspace(n)
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().miq_tensor_minmax(_ptr(x), _FLOAT_CODES[x.dtype], n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def dynamic_epilogue_i8(min_max, w_scale, bias, w_rowsum):
+    """(scale_zp [2], alpha [N], corr [N]) for a weight-only layer run on a per-tensor quantized activation."""
+    require_device(min_max, "min_max")
+    n = w_scale.numel()
+    dev = min_max.device
+    w_scale = w_scale.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    w_rowsum = w_rowsum.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    if bias is not None:
+        bias = bias.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty(2 + 2 * n, dtype=torch.float32, device=dev)
+    scale_zp, alpha, corr = out[:2], out[2:2 + n], out[2 + n:]
+    with torch.cuda.device(dev):
+        _check(lib().miq_dynamic_epilogue_i8(_ptr(min_max), _ptr(w_scale), _ptr(bias), _ptr(w_rowsum), n, _ptr(scale_zp),
+                                             _ptr(alpha), _ptr(corr), _stream()))
+    return scale_zp, alpha, corr
 
 
 def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):

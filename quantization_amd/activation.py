@@ -1,0 +1,72 @@
+"""Dynamic per-tensor int8 quantization of activations, feeding the int8 MFMA GEMM.
+
+The reference configures such a quantizer on every layer (`Quantizer.input_quantizer`: asymmetric,
+per tensor, quant/Weight_Only/Quantizer.py:38-44) but never runs it: its call sites are commented
+out (Quantizer.py:69-70, 88-90) and `Qop.quantize` raises for affine='tensor'
+(Qop.compute_scales_zero_point_dimension indexes `tensor.shape[None]`, Qop.py:110).  This module is
+what those lines compute when followed through with the reference's own formulas, for the signed
+int8 range the MFMA path consumes:
+
+    min, max            over the whole tensor                         (Qop.py:97-99)
+    scale, zero_point   Qop.calculate_params, per-tensor affine branch  (Qop.py:40-41, 62-65)
+    q                   round(x / scale + zero_point).clamp(-128, 127)  (Qop.py:157)
+
+and the layer forward `scale_w[n] * (x_hat . Wq^T + b[n])` of the weight-only Quantizer
+(Quantizer.py:79-86) with x_hat = scale_x * (q - zero_point) in place of x:
+
+    y[m, n] = (acc[m, n] + (b[n] / scale_x - zero_point * rowsum(Wq)[n])) * (scale_w[n] * scale_x)
+
+which is the GEMM's fused epilogue with a per-call bias and alpha.  Nothing here synchronises with
+the host: the two statistics, the parameters and the epilogue vectors stay on the device.
+"""
+import torch
+
+from . import _native
+
+Q_MIN, Q_MAX = -128, 127
+EPS = 2.0 ** -23   # torch.finfo(torch.float32).eps, the reference's floor for a scale (Qop.py:22)
+
+
+@torch.no_grad()
+def tensor_params_i8(x):
+    """(scale [1] fp32, zero_point [1] int32) of x for the int8 range, on x's device."""
+    mm = _native.tensor_minmax(x.contiguous())
+    zero = torch.zeros((), dtype=torch.float32, device=x.device)
+    lo, hi = torch.minimum(mm[0], zero), torch.maximum(mm[1], zero)
+    # tensor / tensor: a division by a Python scalar becomes a multiplication by its reciprocal on the GPU
+    scale = (hi - lo) / torch.full((), float(Q_MAX - Q_MIN), dtype=torch.float32, device=x.device)
+    scale = torch.maximum(scale, torch.full((), EPS, dtype=torch.float32, device=x.device))
+    zp = (Q_MIN - torch.round(lo / scale)).to(torch.int32).clamp(Q_MIN, Q_MAX)
+    return scale.reshape(1), zp.reshape(1)
+
+
+@torch.no_grad()
+def quantize_tensor_i8(x):
+    """x (float) -> (q int8 of x's shape, scale [1], zero_point [1])."""
+    x = x.contiguous()
+    scale, zp = tensor_params_i8(x)
+    rows = x.shape[0] if x.dim() > 1 else 1
+    q = _native.quantize_rows_given_i8(x.reshape(rows, -1), scale, zp.to(torch.float32))
+    return q.view(x.shape), scale, zp
+
+
+@torch.no_grad()
+def weight_rowsum(wq):
+    """sum_k Wq[n, k] as fp32 (exact: |sum| < 2^24 up to K = 131072); compute once per layer."""
+    return wq.reshape(wq.shape[0], -1).sum(dim=1, dtype=torch.int32).to(torch.float32)
+
+
+@torch.no_grad()
+def linear_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, out_dtype=torch.float32):
+    """Weight-only quantized Linear on a float activation, through the int8 GEMM: x is quantized per
+    tensor on the fly and the zero-point correction, both scales and the bias ride the fused epilogue.
+    Five launches, nothing on the host: min/max (two), parameters + epilogue vectors, quantize, GEMM."""
+    _native.require_device(x, "input")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    if w_rowsum is None:
+        w_rowsum = weight_rowsum(wq)
+    scale_zp, alpha, corr = _native.dynamic_epilogue_i8(_native.tensor_minmax(x2), w_scale, bias, w_rowsum)
+    xq = _native.quantize_rows_given_i8(x2, scale_zp[0:1], scale_zp[1:2])
+    y = _native.gemm_i8(xq, wq, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
+    return y.view(*lead, y.shape[-1])

@@ -1,0 +1,211 @@
+// Whole-tensor minimum and maximum: the reduction behind the per-tensor branch of
+// Qop.compute_scales_zero_point (quant/Weight_Only/Qop.py:97-99: tensor.max(), tensor.min()), which
+// the reference's activation quantizer is configured with (quant/Weight_Only/Quantizer.py:38-43).
+// HBM-bandwidth bound: one read of the tensor with 16-byte loads; every workgroup leaves one
+// (min, max) pair in the workspace and a second, single-workgroup launch folds the pairs.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "miq_common.h"
+
+namespace {
+
+using namespace miq;
+
+constexpr int kBlock = 256;
+constexpr int kMaxParts = 2048;
+
+template <int DT>
+struct Elems;
+template <>
+struct Elems<MIQ_F32> {
+    static constexpr int kPerVec = 4;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ float load1(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+};
+template <>
+struct Elems<MIQ_F16> {
+    static constexpr int kPerVec = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __half2float(__ushort_as_half(static_cast<unsigned short>(w[i] & 0xffffu)));
+            f[2 * i + 1] = __half2float(__ushort_as_half(static_cast<unsigned short>(w[i] >> 16)));
+        }
+    }
+    static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+        return __half2float(static_cast<const __half*>(p)[i]);
+    }
+};
+template <>
+struct Elems<MIQ_BF16> {
+    static constexpr int kPerVec = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+        return __uint_as_float(static_cast<uint32_t>(static_cast<const unsigned short*>(p)[i]) << 16);
+    }
+};
+
+__device__ __forceinline__ void block_minmax(float& lo, float& hi) {
+    __shared__ float slo[kBlock / 64], shi[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+    hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+}
+
+// parts[2 * b] / parts[2 * b + 1] = min / max of the elements workgroup b visited.
+template <int DT, bool VECTOR>
+__global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const void* __restrict__ x, int64_t n,
+                                                                float* __restrict__ parts) {
+    using E = Elems<DT>;
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(gridDim.x) * kBlock;
+    if constexpr (VECTOR) {
+        const int64_t nvec = n / E::kPerVec;
+        const uint4* src = static_cast<const uint4*>(x);
+        for (int64_t i = tid; i < nvec; i += nthreads) {
+            float f[E::kPerVec];
+            E::unpack(src[i], f);
+#pragma unroll
+            for (int e = 0; e < E::kPerVec; ++e) {
+                lo = fminf(lo, f[e]);
+                hi = fmaxf(hi, f[e]);
+            }
+        }
+        for (int64_t i = nvec * E::kPerVec + tid; i < n; i += nthreads) {   // tail
+            const float v = E::load1(x, i);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const float v = E::load1(x, i);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    block_minmax(lo, hi);
+    if (threadIdx.x == 0) {
+        parts[2 * blockIdx.x] = lo;
+        parts[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void minmax_final_kernel(const float* __restrict__ parts, int nparts,
+                                                              float* __restrict__ out) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+        lo = fminf(lo, parts[2 * i]);
+        hi = fmaxf(hi, parts[2 * i + 1]);
+    }
+    block_minmax(lo, hi);
+    if (threadIdx.x == 0) {
+        out[0] = lo;
+        out[1] = hi;
+    }
+}
+
+// scale_zp[0] = scale, scale_zp[1] = zero point (as a float) of the per-tensor affine int8 form
+// (Qop.calculate_params, quant/Weight_Only/Qop.py:40-41, 62-65), and the epilogue vectors of a
+// weight-only layer evaluated on the dequantized activation:
+//   alpha[n] = w_scale[n] * scale,   corr[n] = bias[n] / scale - zero_point * w_rowsum[n].
+__global__ __launch_bounds__(kBlock) void dynamic_epilogue_kernel(const float* __restrict__ min_max,
+                                                                  const float* __restrict__ w_scale,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ w_rowsum, int64_t n,
+                                                                  float* __restrict__ scale_zp,
+                                                                  float* __restrict__ alpha, float* __restrict__ corr) {
+    const float lo = fminf(min_max[0], 0.0f), hi = fmaxf(min_max[1], 0.0f);
+    const float scale = fmaxf(__fsub_rn(hi, lo) / 255.0f, 1.1920928955078125e-07f);
+    float zp = __fsub_rn(-128.0f, rintf(lo / scale));
+    zp = fminf(fmaxf(truncf(zp), -128.0f), 127.0f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale_zp[0] = scale;
+        scale_zp[1] = zp;
+    }
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        alpha[i] = __fmul_rn(w_scale[i], scale);
+        const float c = __fmul_rn(-zp, w_rowsum[i]);
+        corr[i] = bias ? __fadd_rn(c, bias[i] / scale) : c;
+    }
+}
+
+int parts_for(int64_t n) {
+    const int64_t want = ceil_div(n, static_cast<int64_t>(kBlock) * 32);   // >= 32 elements per thread
+    return static_cast<int>(want < 1 ? 1 : want > kMaxParts ? kMaxParts : want);
+}
+
+template <int DT>
+void launch_partial(const void* x, int64_t n, float* parts, int nparts, hipStream_t st) {
+    if (aligned(x, 16)) {
+        minmax_partial_kernel<DT, true><<<nparts, kBlock, 0, st>>>(x, n, parts);
+    } else {
+        minmax_partial_kernel<DT, false><<<nparts, kBlock, 0, st>>>(x, n, parts);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t miq_tensor_minmax_workspace(int64_t n) {
+    return n > 0 ? static_cast<size_t>(parts_for(n)) * 2 * sizeof(float) : 0;
+}
+
+extern "C" int miq_tensor_minmax(const void* x, int x_dtype, int64_t n, float* min_max, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    MIQ_REQUIRE(n > 0, MIQ_EINVAL, "miq_tensor_minmax: the tensor is empty (n=%lld)", (long long)n);
+    MIQ_REQUIRE(x && min_max, MIQ_EINVAL, "miq_tensor_minmax: null pointer");
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_tensor_minmax: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    MIQ_REQUIRE(aligned(x, x_dtype == MIQ_F32 ? 4 : 2) && aligned(min_max, 4), MIQ_EALIGN,
+                "miq_tensor_minmax: x / min_max not aligned to their element size");
+    const size_t need = miq_tensor_minmax_workspace(n);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need && aligned(workspace, 4), MIQ_EWORKSPACE,
+                "miq_tensor_minmax: this call needs %zu bytes of 4-byte aligned workspace (got %zu)", need, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    float* parts = static_cast<float*>(workspace);
+    const int nparts = parts_for(n);
+    switch (x_dtype) {
+        case MIQ_F32: launch_partial<MIQ_F32>(x, n, parts, nparts, st); break;
+        case MIQ_F16: launch_partial<MIQ_F16>(x, n, parts, nparts, st); break;
+        default: launch_partial<MIQ_BF16>(x, n, parts, nparts, st); break;
+    }
+    if (int rc = check_launch("minmax_partial_kernel")) return rc;
+    minmax_final_kernel<<<1, kBlock, 0, st>>>(parts, nparts, min_max);
+    return check_launch("minmax_final_kernel");
+}
+
+extern "C" int miq_dynamic_epilogue_i8(const float* min_max, const float* w_scale, const float* bias,
+                                       const float* w_rowsum, int64_t n, float* scale_zp, float* alpha, float* corr,
+                                       void* stream) {
+    MIQ_REQUIRE(n >= 0, MIQ_EINVAL, "miq_dynamic_epilogue_i8: negative size");
+    MIQ_REQUIRE(min_max && scale_zp && (n == 0 || (w_scale && w_rowsum && alpha && corr)), MIQ_EINVAL,
+                "miq_dynamic_epilogue_i8: null pointer");
+    MIQ_REQUIRE(aligned(min_max, 4) && aligned(w_scale, 4) && aligned(bias, 4) && aligned(w_rowsum, 4) &&
+                    aligned(scale_zp, 4) && aligned(alpha, 4) && aligned(corr, 4),
+                MIQ_EALIGN, "miq_dynamic_epilogue_i8: pointers must be 4-byte aligned");
+    const int64_t blocks = ceil_div(n > 0 ? n : 1, kBlock);
+    dynamic_epilogue_kernel<<<static_cast<int>(blocks < 1024 ? blocks : 1024), kBlock, 0, as_stream(stream)>>>(
+        min_max, w_scale, bias, w_rowsum, n, scale_zp, alpha, corr);
+    return check_launch("dynamic_epilogue_kernel");
+}

@@ -184,6 +184,18 @@ class WeightOnlyQuantizer(_QuantizerBase):
         if not (wq.symmetric and wq.dtype == torch.int8):
             # zero_point is identically 0 for symmetric int8, the only form quantize() produces
             raise NotImplementedError("only symmetric int8 weights are implemented")
+        if self.input_quant and not self.cnn and x.dtype.is_floating_point:
+            # The step the reference leaves commented out (Quantizer.py:69-70): quantize the activation per
+            # tensor and take the int8 product (see quantization_amd/activation.py).  Linear only: an
+            # asymmetric activation needs its zero point, not 0, as the convolution's padding value.
+            from .activation import linear_dynamic_w8a8, weight_rowsum
+            home = x.device
+            w = _to_gpu(self.weight)
+            if getattr(self, "_rowsum_src", None) is not self.weight:
+                self._rowsum, self._rowsum_src = weight_rowsum(w), self.weight
+            bias = None if self.bias is None else _to_gpu(self.bias.detach())
+            y = linear_dynamic_w8a8(_to_gpu(x).to(torch.float32), w, _to_gpu(wq.scales), bias, self._rowsum)
+            return y.to(home)
         y = self._run(x, self.bias, wq.scales, 0.0)
         # the reference's dequantize(activation=True) leaves the parameters re-viewed [1,N,...] (Qop.py:175-177)
         if wq.affine == "channel" and wq.scales.dim() > 1 and wq.scales.shape[1] == 1:

@@ -95,6 +95,33 @@ def bench_conv():
             print(f"conv B={B} {C}->{Co} {H}x{H} k{k}s{s}p{p} out={str(od)[6:]}: med {med*1e3:.1f} us  {ops/med/1e9:.0f} TOPS", flush=True)
 
 
+def bench_act():
+    from quantization_amd.activation import linear_dynamic_w8a8, quantize_tensor_i8
+    for shape, dt in (((8192, 8192), torch.float32), ((8192, 8192), torch.bfloat16), ((256, 4096), torch.float32)):
+        xs = [torch.randn(shape, device="cuda").to(dt) for _ in range(5)]   # rotate past the cache for the big case
+        cnt = [0]
+
+        def mm():
+            cnt[0] += 1
+            N.tensor_minmax(xs[cnt[0] % 5])
+
+        def qt():
+            cnt[0] += 1
+            quantize_tensor_i8(xs[cnt[0] % 5])
+        med, _ = timeit(mm)
+        nb = xs[0].numel() * xs[0].element_size()
+        print(f"minmax {shape} {str(dt)[6:]}: med {med*1e3:.1f} us  {nb/med/1e6:.0f} GB/s", flush=True)
+        med, _ = timeit(qt)
+        print(f"quantize_tensor {shape} {str(dt)[6:]} (min/max + params + quantize): med {med*1e3:.1f} us  "
+              f"{(2*nb + xs[0].numel())/med/1e6:.0f} GB/s (2 reads + 1 int8 write)", flush=True)
+    for M in (16, 256, 2048):
+        x = torch.randn(M, 4096, device="cuda")
+        wq, ws, _ = N.quantize_rows_sym_i8(torch.randn(14336, 4096, device="cuda") * 0.02)
+        rs = wq.sum(dim=1, dtype=torch.int32).float()
+        med, _ = timeit(lambda: linear_dynamic_w8a8(x, wq, ws, None, rs))
+        print(f"linear_dynamic_w8a8 M={M} [14336,4096]: med {med*1e3:.1f} us", flush=True)
+
+
 def bench_pool():
     for mode, dt, shape, k, st, p in (("max", torch.int8, (256, 64, 112, 112), 3, 2, 1), ("max", torch.float32, (256, 64, 112, 112), 3, 2, 1),
                                       ("avg", torch.float32, (256, 128, 56, 56), 2, 2, 0), ("avg", torch.int8, (256, 512, 7, 7), 7, 1, 0)):
@@ -106,7 +133,7 @@ def bench_pool():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quant", "gemm", "conv", "small", "pool"]
+    which = sys.argv[1:] or ["quant", "gemm", "conv", "small", "pool", "act"]
     t0 = time.time()
     if "quant" in which:
         bench_quant()
@@ -118,4 +145,6 @@ if __name__ == "__main__":
         bench_conv()
     if "pool" in which:
         bench_pool()
+    if "act" in which:
+        bench_act()
     print(f"done in {time.time()-t0:.1f}s")
