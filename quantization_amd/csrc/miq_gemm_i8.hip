@@ -55,7 +55,13 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ti
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+// STAGES = 2: double buffer, one __syncthreads per K-tile (which also drains the DMA: the fetch of
+// tile t+1 only overlaps the MFMAs of tile t).  STAGES > 2: a ring of K-tile buffers with STAGES-1
+// tiles in flight and a counted vmcnt, for the thin problems (M <= 128) whose K-tile of MFMAs is far
+// shorter than a fetch: per K-tile, wait until all but the newest STAGES-2 tiles have landed, one raw
+// barrier (tile t visible to every wave, tile t-1 read by every wave), re-stage tile t-1's buffer with
+// tile t+STAGES-1, then the MFMAs of tile t.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, int STAGES = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave output tile
@@ -87,17 +93,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     if (g.kt_per_split) g.out = static_cast<int*>(g.out) + static_cast<size_t>(blockIdx.y) * g.M * g.N;
     const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
 
-    stage_tile<BM, NWAVES>(ra, smem, m0, g.M, g.K, kt0, wave, lane);
-    stage_tile<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.N, g.K, kt0, wave, lane);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        char* cur = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * STAGE;
-            stage_tile<BM, NWAVES>(ra, nxt, m0, g.M, g.K, kt0 + t + 1, wave, lane);
-            stage_tile<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.N, g.K, kt0 + t + 1, wave, lane);
-        }
+    auto stage = [&](char* buf, int kt) {
+        stage_tile<BM, NWAVES>(ra, buf, m0, g.M, g.K, kt, wave, lane);
+        stage_tile<BN, NWAVES>(rw, buf + BM * kTileK, n0, g.N, g.K, kt, wave, lane);
+    };
+    auto mma_tile = [&](const char* cur) {
         const char* at = cur + wm * WM * kTileK;
         const char* wt = cur + BM * kTileK + wn * WN * kTileK;
 #pragma unroll
@@ -114,7 +114,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // stage t+1 landed (LDS-DMA drained) and stage t fully read
+    };
+
+    if constexpr (STAGES == 2) {
+        stage(smem, kt0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) stage(smem + ((t + 1) & 1) * STAGE, kt0 + t + 1);
+            mma_tile(smem + (t & 1) * STAGE);
+            __syncthreads();  // stage t+1 landed (LDS-DMA drained) and stage t fully read
+        }
+    } else {
+        // every wave issues the same number of DMA instructions per K-tile, so one count serves all
+        static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "pieces must divide among the waves");
+        constexpr int kLoads = (BM / 8 + BN / 8) / NWAVES;
+        constexpr int kKeep = kLoads * (STAGES - 2);
+        static_assert(kKeep <= 63, "vmcnt is a 6-bit counter");
+        const int kt_end = kt0 + nt;   // tiles past the slice are requested past K: zero-filled, no traffic
+        auto stage_or_skip = [&](char* buf, int kt) { stage(buf, kt < kt_end ? kt : nt_all); };
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) stage_or_skip(smem + s * STAGE, kt0 + s);
+        int slot = 0, fill = STAGES - 1;   // buffer of tile t; buffer tile t + STAGES - 1 goes into
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKeep) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage_or_skip(smem + fill * STAGE, kt0 + t + STAGES - 1);
+            mma_tile(smem + slot * STAGE);
+            slot = slot + 1 == STAGES ? 0 : slot + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // Epilogue.  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
@@ -753,18 +783,18 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, int STAGES = 2>
 int launch_tile(GemmArgs g, hipStream_t st, int splits = 1, int kt_per_split = 0, int* slabs = nullptr) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
-    constexpr int kLds = 2 * (BM + BN) * kTileK;
+    constexpr int kLds = STAGES * (BM + BN) * kTileK;
     const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_gemm_i8: too many tiles");
     if (splits > 1) {
         GemmArgs part = g;
         part.out = slabs;
         part.kt_per_split = kt_per_split;
-        auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, kOutI32>;
+        auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, kOutI32, STAGES>;
         if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
         kern<<<dim3(static_cast<unsigned>(nwg), static_cast<unsigned>(splits)), 64 * WAVES_M * WAVES_N, kLds, st>>>(part);
         if (int rc = check_launch("gemm_i8_kernel (split-K)")) return rc;
@@ -773,7 +803,7 @@ int launch_tile(GemmArgs g, hipStream_t st, int splits = 1, int kt_per_split = 0
         splitk_reduce_kernel<OUT><<<rgrid, 256, 0, st>>>(slabs, splits, g);
         return check_launch("splitk_reduce_kernel");
     }
-    auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT>;
+    auto kern = gemm_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, STAGES>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
     return check_launch("gemm_i8_kernel");
@@ -837,9 +867,16 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             default: break;
         }
     }
+    const char* stg = getenv("MIQ_GEMM_STAGES");   // developer A/B switch: 2 = double-buffered kernels
+    if (stg && stg[0] == '2') {
+        if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+        if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+    }
+    // 128 x 128: double-buffered (two workgroups per CU at 64 KiB each beat one with a 96 KiB ring: 18 vs 24 us
+    // at M = 128 on [14336, 4096]); 64- and 32-row tiles: four-deep ring (12-14 vs 18-20 us unsplit).
     if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
-    if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
-    if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
+    if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
+    if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
     return launch_tile<16, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
 }
 
