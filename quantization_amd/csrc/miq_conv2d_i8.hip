@@ -14,6 +14,7 @@
 // so a lane holds four consecutive pixels of one output channel: a 16-byte NCHW store.
 //
 // Replaces conv2d_kernel_int8 / conv2d_int8 (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:6-114).
+#include <algorithm>
 #include <cstdlib>
 
 #include "miq_common.h"
@@ -98,16 +99,15 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint3
 // aligned base; single bytes otherwise), transposes it in registers, and the dwords go through a
 // 4 KiB LDS tile laid out [pixel][channel] so that each thread can store 16 channel bytes of one
 // pixel.  The 16-byte groups of a tile row are XOR-ed with the pixel's dword index to spread the
-// writes over the banks.  The zero border is written by nhwc_border_kernel.
+// writes over the banks.  The zero border is written by nhwc_border_items.
 template <bool DWORD>
-__global__ __launch_bounds__(256) void nhwc_interior_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ xp,
-                                                            int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                            int cblocks) {
+__device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin, int H,
+                                                    int W, int Hp, int Wp, int Cp, int pad, int cblocks, int bx,
+                                                    int64_t b) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 16];
     const int t = threadIdx.x;
     const int HW = H * W;
-    const int p0 = (blockIdx.x / cblocks) * 64, c0 = (blockIdx.x % cblocks) * 64;
-    const int64_t b = blockIdx.y;
+    const int p0 = (bx / cblocks) * 64, c0 = (bx % cblocks) * 64;
     const int cspan = Cp - c0 < 64 ? Cp - c0 : 64;   // channel bytes this block owns per pixel (multiple of 4)
     {
         const int p4 = t & 15, cg = t >> 4;
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256) void nhwc_interior_kernel(const int8_t* __rest
 }
 
 // Zeros in the `pad` rows above and below and the `pad` columns left and right of every image.
-__global__ __launch_bounds__(256) void nhwc_border_kernel(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp,
-                                                          int pad, int64_t total) {
+__device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp, int pad,
+                                                  int64_t total, int64_t first, int64_t step) {
     const int cdw = Cp >> 2;
     const int per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
-    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+    for (int64_t idx = first; idx < total; idx += step) {
         const int dw = static_cast<int>(idx % cdw);
         const int e = static_cast<int>((idx / cdw) % per_image);
         const int64_t b = idx / (static_cast<int64_t>(cdw) * per_image);
@@ -200,10 +200,10 @@ __global__ __launch_bounds__(256) void nhwc_pad_c4_kernel(const int8_t* __restri
 }
 
 // OIHW -> wp[Cout][KH][Lp] with (kw, c) order inside a filter row and zero fill.
-__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
-                                                               int64_t total, int Cin, int KH, int KW, int Cp, int L,
-                                                               int Lp) {
-    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+__device__ __forceinline__ void pack_conv_weight_items(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
+                                                       int64_t total, int Cin, int KH, int KW, int Cp, int L, int Lp,
+                                                       int64_t first, int64_t step) {
+    for (int64_t idx = first; idx < total; idx += step) {
         const int l = static_cast<int>(idx % Lp);
         const int kh = static_cast<int>((idx / Lp) % KH);
         const int64_t n = idx / (static_cast<int64_t>(Lp) * KH);
@@ -214,6 +214,45 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __r
         }
         wp[idx] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
+                                                               int64_t total, int Cin, int KH, int KW, int Cp, int L,
+                                                               int Lp) {
+    pack_conv_weight_items(w, wp, total, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256ll + threadIdx.x, 256ll * gridDim.x);
+}
+
+template <bool DWORD>
+__global__ __launch_bounds__(256) void nhwc_interior_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ xp,
+                                                            int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
+                                                            int cblocks) {
+    nhwc_interior_block<DWORD>(x, xp, Cin, H, W, Hp, Wp, Cp, pad, cblocks, blockIdx.x, blockIdx.y);
+}
+
+// Everything a convolution call does before its MFMA kernel, in one launch: workgroups
+// [0, n_interior) of every image re-lay the interior (nhwc_interior_block); the n_extra workgroups
+// after them share, across all images, the zero border of the padded copy and the weight re-layout.
+struct ConvPrepArgs {
+    const int8_t* x;
+    int8_t* xp;
+    const int8_t* w;
+    int8_t* wp;
+    int Cin, H, W, Hp, Wp, Cp, pad, cblocks;
+    int KH, KW, L, Lp;
+    int n_interior, n_extra;
+    int64_t border_total, weight_total;
+};
+
+template <bool DWORD>
+__global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
+    if (static_cast<int>(blockIdx.x) < a.n_interior) {
+        nhwc_interior_block<DWORD>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y);
+        return;
+    }
+    const int64_t first = (static_cast<int64_t>(blockIdx.y) * a.n_extra + (blockIdx.x - a.n_interior)) * 256 + threadIdx.x;
+    const int64_t step = static_cast<int64_t>(gridDim.y) * a.n_extra * 256;
+    nhwc_border_items(a.xp, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.border_total, first, step);
+    pack_conv_weight_items(a.w, a.wp, a.weight_total, a.Cin, a.KH, a.KW, a.Cp, a.L, a.Lp, first, step);
 }
 
 struct ConvArgs {
@@ -521,36 +560,43 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
     int8_t* wp = xp + miq::round_up(G.xp_bytes, 256);
     {
         const int cblocks = static_cast<int>(miq::ceil_div(G.Cp, 64));
+        bool packed = false;   // the weight re-layout rode along with the activation re-layout
         dim3 grid(static_cast<unsigned>(miq::ceil_div(G.Wp, 64) * cblocks), static_cast<unsigned>(G.Hp),
                   static_cast<unsigned>(B));
         if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4) {
             const int64_t total4 = B * G.Hp * (W / 4);
             const int g4 = static_cast<int>(total4 / 256 + 1 < (1 << 20) ? total4 / 256 + 1 : (1 << 20));
             nhwc_pad_c4_kernel<<<g4, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)pad, total4);
-        } else if (H * W < (1ll << 30)) {
-            dim3 fgrid(static_cast<unsigned>(miq::ceil_div(H * W, 64) * cblocks), static_cast<unsigned>(B));
+        } else if (H * W < (1ll << 30) && B < 65536) {
+            ConvPrepArgs pa{};
+            pa.x = x; pa.xp = xp; pa.w = w; pa.wp = wp;
+            pa.Cin = (int)Cin; pa.H = (int)H; pa.W = (int)W; pa.Hp = (int)G.Hp; pa.Wp = (int)G.Wp; pa.Cp = (int)G.Cp;
+            pa.pad = (int)pad; pa.cblocks = cblocks;
+            pa.KH = (int)KH; pa.KW = (int)KW; pa.L = (int)G.L; pa.Lp = (int)G.Lp;
+            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
+            pa.border_total = B * (2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 4);
+            pa.weight_total = G.wp_bytes;
+            // about four border dwords / weight bytes per extra thread, spread over the images' grid rows
+            const int64_t extra = miq::ceil_div(pa.border_total + pa.weight_total, 1024);
+            pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
+            dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if ((H * W) % 4 == 0 && miq::aligned(x, 4))
-                nhwc_interior_kernel<true><<<fgrid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp,
-                                                                  (int)G.Cp, (int)pad, cblocks);
+                conv_prep_kernel<true><<<pgrid, 256, 0, st>>>(pa);
             else
-                nhwc_interior_kernel<false><<<fgrid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp,
-                                                                   (int)G.Cp, (int)pad, cblocks);
-            if (pad > 0) {
-                if (int rc = miq::check_launch("nhwc_interior_kernel")) return rc;
-                const int64_t btotal = B * (2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 4);
-                const int bg = static_cast<int>(btotal / 256 + 1 < 65536 ? btotal / 256 + 1 : 65536);
-                nhwc_border_kernel<<<bg, 256, 0, st>>>(xp, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, btotal);
-            }
+                conv_prep_kernel<false><<<pgrid, 256, 0, st>>>(pa);
+            packed = true;
         } else {
             nhwc_pad_kernel<<<grid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp,
                                                   (int)pad, cblocks);
         }
-        if (int rc = miq::check_launch("nhwc_pad_kernel")) return rc;
-        const int64_t total = G.wp_bytes;
-        const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
-        pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
-                                                       (int)G.Lp);
-        if (int rc = miq::check_launch("pack_conv_weight_kernel")) return rc;
+        if (int rc = miq::check_launch("nhwc re-layout kernel")) return rc;
+        if (!packed) {
+            const int64_t total = G.wp_bytes;
+            const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+            pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
+                                                           (int)G.Lp);
+            if (int rc = miq::check_launch("pack_conv_weight_kernel")) return rc;
+        }
     }
 
     ConvArgs a{};
