@@ -13,10 +13,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization_amd import _native as N  # noqa: E402
 
 
-def timeit(fn, iters=20, warmup=5):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
+def timeit(fn, iters=20, warmup=5, ramp_s=0.15):
+    """Median and minimum of `iters` single launches timed with HIP events, after `ramp_s` seconds of the
+    same launches: the chip needs tens of milliseconds of load to leave its idle clocks."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in evs:
         s.record()

@@ -17,7 +17,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetc
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o p -- python3 bench.py --no-cpu-baseline --steps 5 > "$out/write.log" 2>&1 || { echo "write pass failed"; tail -5 "$out/write.log"; exit 1; }
 timeout -k 10 300 python3 tools/kbench.py > "$out/kbench.txt" 2>&1 || { echo "kbench failed"; tail -5 "$out/kbench.txt"; exit 1; }
 python3 - "$out" <<'EOF'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections, statistics
 out = sys.argv[1]
 res = {}
 for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -29,7 +29,7 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for k, v in acc.items():
         for short in ("quantize_rows_reg_kernel", "gemm_i8_256_kernel"):
             if short in k:
-                res.setdefault(short, {})[key] = sum(v) / len(v)
+                res.setdefault(short, {})[key] = statistics.median(v)   # the bench shape; stray launches of other shapes drop out
 for short, d in res.items():
     f, w = d.get("FETCH_SIZE", 0.0) * 2.0, d.get("WRITE_SIZE", 0.0)   # gfx950: FETCH_SIZE counts 64 B per 128-B request
     d.update({"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
