@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MIQ_VERSION 100 /* major*10000 + minor*100 + patch */
+#define MIQ_VERSION 200 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define MIQ_OK 0

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/miq.h but not exported"
     assert sorted(_native.SYMBOLS) == declared, "ctypes table and header disagree"
-    assert lib.miq_version() == 100
+    assert lib.miq_version() == 200
 
 
 def test_argument_validation_needs_no_device():
