@@ -470,10 +470,22 @@ template <int OUT>
 int launch(const ConvArgs& g, hipStream_t st) {
     // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
     auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
-    if (g.Cout > 128 && tiles(256, 256) >= 200) return launch_tile<256, 256, 2, 4, OUT>(g, st);
-    if (g.Cout > 64 && tiles(256, 128) >= 200) return launch_tile<256, 128, 2, 4, OUT>(g, st);
+    if (const char* force = getenv("MIQ_CONV_TILE")) {   // developer A/B switch
+        switch (force[0]) {
+            case 'a': return launch_tile<256, 256, 2, 4, OUT>(g, st);
+            case 'b': return launch_tile<256, 128, 2, 4, OUT>(g, st);
+            case 'c': return launch_tile<256, 64, 4, 2, OUT>(g, st);
+            case 'd': return launch_tile<128, 128, 2, 2, OUT>(g, st);
+            case 'e': return launch_tile<128, 64, 2, 2, OUT>(g, st);
+            default: break;
+        }
+    }
+    // Measured on the ResNet-18 layers at batch 256 (MIQ_CONV_TILE sweep): 256 x 256 wins once it gives most
+    // CUs a tile (196 tiles: 55 vs 61-66 us on 256->256 14x14); up to 128 output channels the 128 x 64 tile
+    // (three workgroups per CU) beats 256 x 128 and 128 x 128 (69 vs 81 / 76 us on 64->128 3x3/2).
+    if (g.Cout > 128 && tiles(256, 256) >= 160) return launch_tile<256, 256, 2, 4, OUT>(g, st);
+    if (g.Cout > 128) return launch_tile<128, 128, 2, 2, OUT>(g, st);
     if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
-    if (g.Cout > 64) return launch_tile<128, 128, 2, 2, OUT>(g, st);
     return launch_tile<128, 64, 2, 2, OUT>(g, st);
 }
 
