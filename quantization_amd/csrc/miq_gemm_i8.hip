@@ -757,7 +757,9 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
             return p;
         }
     }
-    if (M > 64) {
+    const char* mid = getenv("MIQ_GEMM_MID");   // developer A/B switch: largest M that takes 64-row tiles
+    const int64_t mid_m = mid ? atoll(mid) : 128;
+    if (M > mid_m) {
         p.bm = 128; p.bn = 128;
     } else if (M > 32) {
         p.bm = 64; p.bn = 64;
