@@ -866,6 +866,10 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             case 'f': return launch_tile<256, 64, 4, 2, OUT>(g, st);
             case 'g': return launch_tile<64, 64, 2, 2, OUT>(g, st);
             case 'h': return launch_tile<128, 64, 4, 2, OUT>(g, st);
+            case 'i': return launch_tile<128, 64, 2, 2, OUT, 3>(g, st);
+            case 'j': return launch_tile<128, 64, 4, 2, OUT, 3>(g, st);
+            case 'k': return launch_tile<64, 128, 2, 2, OUT, 3>(g, st);
+            case 'l': return launch_tile<64, 64, 2, 2, OUT, 4>(g, st);
             default: break;
         }
     }
