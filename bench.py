@@ -104,12 +104,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # Rehearsal aid: MIQ_BENCH_BACKEND=gloo runs the N-rank code path with every rank on the one GPU of a
+    # development box (RCCL needs one GPU per rank); the numbers of such a run mean nothing.
+    backend = os.environ.get("MIQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from quantization_amd import _native as N_
     from quantization_amd.sharded import ColumnShardedLinear
@@ -169,9 +177,11 @@ def main():
     # The chip takes tens of milliseconds of load to leave its idle clocks (the same 30 steps measured
     # 0.456 ms each after 5 warm-up steps and 0.408 ms after 100): bring it to its loaded state with the
     # same step before the W warm-up steps, whatever W the caller asks for.
+    # Local GEMMs only: the ranks' loop counts differ, so no collective may be issued here.
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < PREWARM_S:
-        run_steps(10)
+        for _ in range(10):
+            layer.local_forward(x)
         torch.cuda.synchronize()
     run_steps(args.warmup)
     if world > 1:
