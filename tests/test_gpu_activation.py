@@ -97,3 +97,25 @@ def test_quantizer_input_quant_flag():
     assert y_int8.shape == y_float.shape and y_int8.device == x.device
     rel = float((y_int8 - y_float).norm() / y_float.norm())
     assert 0.0 < rel < 0.03, rel
+
+
+def test_activation_entry_points_reject_bad_arguments():
+    """Argument checks of the C entry points, through ctypes: every failure is reported before any launch."""
+    import ctypes
+    from quantization_amd import _native as N
+    lib = N.lib()
+    x = torch.zeros(1024, device="cuda")
+    out = torch.zeros(2, device="cuda")
+    ws = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    assert lib.miq_tensor_minmax(p(x), 0, 0, p(out), p(ws), 64, None) == -1            # empty tensor
+    assert lib.miq_tensor_minmax(p(x), 7, 1024, p(out), p(ws), 64, None) == -1         # unknown dtype
+    assert lib.miq_tensor_minmax(p(x), 0, 1024, p(out), None, 0, None) == -3           # no workspace
+    assert b"workspace" in lib.miq_last_error()
+    assert lib.miq_tensor_minmax(None, 0, 1024, p(out), p(ws), 64, None) == -1         # null input
+    assert lib.miq_tensor_minmax_workspace(0) == 0 and lib.miq_tensor_minmax_workspace(1 << 30) == 2048 * 8
+    assert lib.miq_dynamic_epilogue_i8(None, p(x), None, p(x), 4, p(out), p(x), p(x), None) == -1
+    assert lib.miq_dynamic_epilogue_i8(p(out), p(x), None, p(x), -1, p(out), p(x), p(x), None) == -1
+    assert lib.miq_pool2d_to_i8(p(x), 0, 1, 1, 4, 4, 2, 2, 2, 2, 0, 0, 5, p(ws), None) == -1   # unknown mode
+    assert lib.miq_pool2d_to_i8(p(x), 3, 1, 1, 4, 4, 2, 2, 2, 2, 0, 0, 0, p(ws), None) == -1   # int32 input
+    assert lib.miq_pool2d_to_i8(p(x), 0, 1, 1, 4, 4, 2, 2, 0, 2, 0, 0, 0, p(ws), None) == -1   # zero stride
