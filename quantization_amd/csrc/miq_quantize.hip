@@ -8,7 +8,8 @@
 //
 // Semantics follow the reference's Qop (quant/Weight_Only/Qop.py:37-54, 74-102, 139-162):
 // signed row maximum (not abs-max), divisor 127.5, floor 2^-23, zero point 0 as int64,
-// q = clamp(rint(w / scale)) with a true division.
+// q = clamp(rint(w / scale)) with a true division.  (The kernel multiplies by 1 / scale where it
+// can prove the int8 equal to the true division's and divides otherwise: quantize_vec.)
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -191,8 +192,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Row held in registers.  TPR threads cooperate on one row (64 = one wave, 256 = the whole
-// workgroup); each keeps NV 16-byte vectors.  Rows are walked with a grid stride.
+// Row held in registers.  TPR threads cooperate on one row (64 = one wave, 256 or 1024 = the whole
+// workgroup); each keeps NV 16-byte vectors.  The launcher gives every row group its own workgroup
+// (the loop below runs once); the stride form only keeps the kernel correct for any grid.
 template <int DT, int NV, int TPR, bool NT = false, int BLOCK = (TPR > kBlock ? TPR : kBlock)>
 __global__ __launch_bounds__(BLOCK) void quantize_rows_reg_kernel(const uint4* __restrict__ w,
                                                                    int64_t rows, int nvec, int8_t* __restrict__ q,

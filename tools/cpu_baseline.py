@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The reference's CPU path (oracle/oracle_torch.py, pinned to the reference by fixtures) timed on
-this machine's host cores, for the table in DESIGN.md: quantizer, weight-only forward, an int32
+this machine's host cores: quantizer, weight-only forward, an int32
 matmul standing in for linear_w8a8, and a ResNet-18 layer as F.conv2d.
 
     python tools/cpu_baseline.py [threads]
