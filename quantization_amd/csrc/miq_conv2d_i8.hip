@@ -272,6 +272,7 @@ struct ConvArgs {
     uint32_t cps_magic;       // floor(2^32 / cps) + 1: q / cps == umulhi(q, cps_magic) for q < 2^16, cps > 1
     uint32_t xp_bytes, wp_bytes;
     int stream_out;           // 1: nontemporal 16-byte output stores (outputs far larger than the 256 MiB cache)
+    int wide16;               // bf16 output: eight pixels per 16-byte store (HoWo % 8 == 0, 16-byte aligned output)
     int tiles_m, tiles_n;
 };
 
@@ -393,12 +394,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = nbase + j * 16;
-        if (n >= g.Cout) continue;
         float al = 1.f, bi = 0.f;
         if constexpr (OUT != kOutI32) {
-            al = g.alpha[n];
-            if (g.bias) bi = g.bias[n];
+            if (n < g.Cout) {
+                al = g.alpha[n];
+                if (g.bias) bi = g.bias[n];
+            }
         }
+        if constexpr (OUT == kOutBF16 && FM % 2 == 0) {
+            // Four bf16 pixels are only 8 bytes: two neighbouring pixel fragments trade 16-lane rows, and a
+            // lane stores eight consecutive pixels of its channel as one 16-byte vector (a channel's 32
+            // pixels of the pair leave as one 64-byte segment, in half the store instructions).
+            if (g.wide16) {   // HoWo % 8 == 0 and a 16-byte aligned output: eight pixels share an image
+#pragma unroll
+                for (int i = 0; i < FM; i += 2) {
+                    uint2 p[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const v4i a = acc[i + h][j];
+                        p[h] = pack4_bf16(dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                          dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
+                    }
+                    const v4i v = pair_rows_bf16(p[0], p[1]);
+                    const int m = m0 + wm * WM + i * 16 + paired_offset(lane);
+                    if (m >= g.M || n >= g.Cout) continue;
+                    const int b = m / g.HoWo, px = m % g.HoWo;
+                    v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) +
+                                                    (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + px);
+                    if constexpr (STREAM) {
+                        __builtin_nontemporal_store(v, o);
+                    } else {
+                        *o = v;
+                    }
+                }
+                continue;
+            }
+        }
+        if (n >= g.Cout) continue;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = mbase + i * 16;
@@ -424,12 +456,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
                         *o = y;
                     }
                 } else {
-                    uint2 pk;
-                    pk.x = f32_to_bf16_bits(dequant1(a[0], bi, al, g.beta)) |
-                           (static_cast<uint32_t>(f32_to_bf16_bits(dequant1(a[1], bi, al, g.beta))) << 16);
-                    pk.y = f32_to_bf16_bits(dequant1(a[2], bi, al, g.beta)) |
-                           (static_cast<uint32_t>(f32_to_bf16_bits(dequant1(a[3], bi, al, g.beta))) << 16);
-                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) = pk;
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) =
+                        pack4_bf16(dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                   dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
                 }
             } else {
 #pragma unroll
@@ -453,14 +482,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tile(ConvArgs g, hipStream_t st) {
-    constexpr bool kCanStream = OUT != kOutBF16;   // 8-byte nontemporal stores are slower than cached ones
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
     const int lds = 2 * (BM + BN) * kTileK;
     auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false>;
-    if constexpr (kCanStream) {
-        if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
-    }
+    if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
     return check_launch("conv_i8_kernel");
@@ -634,7 +660,9 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
     // Measured at batch 256 with the output rotating over three buffers: nontemporal stores gain 14 % on the
     // 822 MB output of ResNet-18's first layer and 3 % at 205 MB, and lose 8-40 % on outputs of 26-103 MB,
     // which the Infinity Cache absorbs.
-    a.stream_out = G.M * Cout * 4 >= (192ll << 20);
+    a.wide16 = out_dtype == MIQ_BF16 && a.HoWo % 8 == 0 && miq::aligned(out, 16);
+    // (8-byte nontemporal stores are slower than cached ones: bf16 outputs stream only as 16-byte vectors.)
+    a.stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16);
     switch (out_dtype) {
         case MIQ_F32:
             return launch<kOutF32>(a, st);

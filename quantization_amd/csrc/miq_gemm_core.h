@@ -76,11 +76,37 @@ __device__ __forceinline__ void tile_coords(int pid, int nwg, int tiles_m, int t
 
 enum : int { kOutF32 = 0, kOutBF16 = 2, kOutI32 = 3 };  // == MIQ_F32 / MIQ_BF16 / MIQ_I32
 
+// fp32 -> bf16, round-half-even, NaN stays NaN: the hardware conversion (v_cvt_pk_bf16_f32, two values
+// per instruction) instead of a dozen integer operations per value.
+typedef __bf16 miq_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float miq_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(miq_f32x2{a, b}, miq_bf16x2));
+}
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float x) {
-    uint32_t u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
+    return __builtin_bit_cast(uint16_t, static_cast<__bf16>(x));
+}
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    uint2 p;
+    p.x = pack2_bf16(a, b);
+    p.y = pack2_bf16(c, d);
+    return p;
+}
+
+// Two MFMA result fragments X and Y, each packed as four bf16 (8 bytes) per lane, where the 16-lane row
+// c = lane >> 4 of a fragment holds elements 4c .. 4c+3 of its 16 along the register axis.  Rows trade
+// places (v_permlane16_swap: the odd rows of one operand with the even rows of the other) so that every
+// lane ends up with eight consecutive elements of ONE fragment, 16 bytes: rows 0 and 2 hold elements 0-7
+// and 8-15 of X, rows 1 and 3 those of Y.  paired_offset() is the element offset of a lane's eight, with
+// Y's elements counted from 16 (Y follows X along the register axis).
+__device__ __forceinline__ v4i pair_rows_bf16(uint2 x, uint2 y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+    return v4i{static_cast<int>(lo[0]), static_cast<int>(hi[0]), static_cast<int>(lo[1]), static_cast<int>(hi[1])};
+}
+__device__ __forceinline__ int paired_offset(int lane) {
+    const int c = lane >> 4;
+    return (c & 1) * 16 + (c >> 1) * 8;
 }
 
 // (float(acc) + bias) * alpha + beta with one rounding per step (no contraction), the order

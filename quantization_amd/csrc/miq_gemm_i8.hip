@@ -194,10 +194,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
                 } else {
                     uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
                     if (vec_ok && n + 3 < g.N) {
-                        uint2 p;
-                        p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
-                        p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
-                        *reinterpret_cast<uint2*>(o) = p;
+                        *reinterpret_cast<uint2*>(o) = pack4_bf16(y[0], y[1], y[2], y[3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -211,24 +208,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
 
 // Epilogue of a 256 x 256 tile held as acc[qm][qn][i][j] by 8 waves (2 x 4).  D[i][j] of a fragment:
 // i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
-template <int OUT, bool NT = true>
+//
+// bf16 outputs: a lane's four channels of one fragment are only 8 bytes, so the fragments j = 0, 1 of a
+// row group (channels 0-15 and 16-31 of the wave's 32) first trade 16-lane rows (pair_rows_bf16); every
+// lane then stores eight consecutive channels as one 16-byte vector: half the store instructions, and a
+// row's 32 channels leave as one 64-byte segment.
+template <int OUT, bool NT = true, bool WIDE16 = true>
 __device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&acc)[2][2][4][2], int m0, int n0, int wm,
                                                int wn, int lane) {
     const bool vec_ok = (g.N & 3) == 0;
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
+    for (int qn = 0; qn < 2; ++qn) {
+        const int nb = n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
+        float al[2][4], bi[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
-            float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (OUT != kOutI32) {
+            const int n = nb + j * 16 + (lane >> 4) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
+                al[j][e] = 1.f;
+                bi[j][e] = 0.f;
+                if constexpr (OUT != kOutI32) {
                     if (n + e < g.N) {
-                        al[e] = g.alpha[n + e];
-                        if (g.bias) bi[e] = g.bias[n + e];
+                        al[j][e] = g.alpha[n + e];
+                        if (g.bias) bi[j][e] = g.bias[n + e];
                     }
+                }
             }
+        }
+        if constexpr (OUT == kOutBF16 && WIDE16) {
+            if ((g.N & 7) == 0 && nb + 32 <= g.N) {   // wave-uniform
+                const int n = nb + paired_offset(lane);
+#pragma unroll
+                for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint2 p[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const v4i a = acc[qm][qn][i][j];
+                            p[j] = pack4_bf16(dequant1(a[0], bi[j][0], al[j][0], g.beta), dequant1(a[1], bi[j][1], al[j][1], g.beta),
+                                              dequant1(a[2], bi[j][2], al[j][2], g.beta), dequant1(a[3], bi[j][3], al[j][3], g.beta));
+                        }
+                        const v4i v = pair_rows_bf16(p[0], p[1]);
+                        const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
+                        if (m >= g.M) continue;
+                        v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) + static_cast<size_t>(m) * g.N + n);
+                        if constexpr (NT) {
+                            __builtin_nontemporal_store(v, o);
+                        } else {
+                            *o = v;
+                        }
+                    }
+                continue;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb + j * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -253,7 +290,7 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&ac
                     } else {
                         float y[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
+                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[j][e], al[j][e], g.beta);
                         if constexpr (OUT == kOutF32) {
                             float* o = static_cast<float*>(g.out) + idx;
                             if (vec_ok && n + 3 < g.N) {
@@ -273,11 +310,8 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&ac
                         } else {
                             uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
                             if (vec_ok && n + 3 < g.N) {
-                                uint2 p;
-                                p.x = f32_to_bf16_bits(y[0]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[1])) << 16);
-                                p.y = f32_to_bf16_bits(y[2]) | (static_cast<uint32_t>(f32_to_bf16_bits(y[3])) << 16);
                                 // cached: as 8-byte nontemporal stores this epilogue ran 23 % slower (measured)
-                                *reinterpret_cast<uint2*>(o) = p;
+                                *reinterpret_cast<uint2*>(o) = pack4_bf16(y[0], y[1], y[2], y[3]);
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
@@ -287,6 +321,7 @@ __device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&ac
                     }
                 }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -566,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
 
-    store_tile_256<OUT, (ABL & 256) == 0>(g, acc, m0, n0, wm, wn, lane);
+    store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0>(g, acc, m0, n0, wm, wn, lane);
 }
 
 // Any K and any alignment: one thread per output element.  Only shapes the MFMA path cannot
@@ -833,6 +868,8 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         auto kern = (var && var[0] == '0') ? gemm_i8_256_kernel<OUT, 0> : gemm_i8_256_kernel<OUT, 2>;
         const char* abl = getenv("MIQ_GEMM_ABL");
         if (abl && abl[0] == 'n') kern = gemm_i8_256_kernel<OUT, 2, 256>;   // plain (cached) epilogue stores
+        if (abl && abl[0] == 'h') kern = gemm_i8_256_kernel<OUT, 2, 512>;   // bf16: 8-byte stores, fragments unpaired
+        if (abl && abl[0] == 'H') kern = gemm_i8_256_kernel<OUT, 2, 512 + 256>;
         if (abl && OUT == kOutF32) {
             if (abl[0] == '1') kern = gemm_i8_256_kernel<OUT, 0, 1>;
             if (abl[0] == '6') kern = gemm_i8_256_kernel<OUT, 0, 8>;

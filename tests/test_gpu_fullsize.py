@@ -119,6 +119,7 @@ def test_gemm_full_size_checksums(N, M, Nn, K):
     np.testing.assert_array_equal(y[ms].cpu().numpy(), ref)
     yb = N.gemm_i8(a, w, bias=bias, alpha=alpha, beta=0.25, out_dtype=torch.bfloat16)
     np.testing.assert_array_equal(yb[ms].float().cpu().numpy(), O.round_f32_to_bf16(ref))
+    assert torch.equal(yb, y.to(torch.bfloat16))   # every element: the fp32 result rounded once (round-half-even)
 
 
 @pytest.mark.parametrize("C,H,Co,k,s,p", [(64, 56, 64, 3, 1, 1), (3, 224, 64, 7, 2, 3), (128, 28, 256, 3, 2, 1),
@@ -134,6 +135,16 @@ def test_conv_resnet18_batch256(N, C, H, Co, k, s, p):
     for b in (0, 137, 255):
         ref = torch.nn.functional.conv2d(x[b:b + 1].double(), w.double(), stride=s, padding=p).to(torch.int32)
         assert torch.equal(out[b:b + 1], ref)
+    # dequantised outputs: fp32 against the oracle's epilogue on a sampled image, bf16 = that fp32 rounded once
+    g = torch.Generator(device="cuda").manual_seed(5)
+    alpha = torch.rand(Co, generator=g, device="cuda") * 1e-3 + 1e-5
+    bias = torch.randn(Co, generator=g, device="cuda") * 100
+    y = N.conv2d_i8(x, w, s, p, bias=bias, alpha=alpha, beta=-0.5)
+    ref = OC.epilogue_f32(out[137].cpu().numpy()[None], bias.cpu().numpy(), alpha.cpu().numpy(), -0.5)
+    np.testing.assert_array_equal(y[137:138].cpu().numpy(), ref)
+    del out
+    yb = N.conv2d_i8(x, w, s, p, bias=bias, alpha=alpha, beta=-0.5, out_dtype=torch.bfloat16)
+    assert torch.equal(yb, y.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("mode,dtype,shape,k,s,p", [("max", torch.int8, (256, 64, 112, 112), 3, 2, 1),

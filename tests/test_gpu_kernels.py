@@ -193,6 +193,22 @@ def test_gemm_epilogue_f32_bit_exact_vs_oracle(N, M, N_, K, with_bias):
     np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
 
 
+@pytest.mark.parametrize("M,N_,K", [(3584, 3600, 64), (3500, 3604, 80), (3584, 3592, 48)])
+def test_gemm_big_tile_ragged_edges(N, M, N_, K):
+    """Shapes that take the 256 x 256 kernel with partial last tiles; N % 8 == 0 (paired 16-byte bf16
+    stores, also next to a ragged last 32-channel group) and N % 8 == 4 (8-byte bf16 stores)."""
+    a, w = rand_i8((M, K), 11 + M), rand_i8((N_, K), 12 + N_)
+    g = torch.Generator().manual_seed(13)
+    alpha, bias = torch.rand(N_, generator=g) * 0.01 + 1e-4, torch.randn(N_, generator=g) * 50
+    acc = OC.linear_i8_nt(a.numpy(), w.numpy())
+    np.testing.assert_array_equal(N.gemm_i8(a.cuda(), w.cuda(), out_dtype=torch.int32).cpu().numpy(), acc)
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), 0.5)
+    out = N.gemm_i8(a.cuda(), w.cuda(), bias=bias.cuda(), alpha=alpha.cuda(), beta=0.5)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    outb = N.gemm_i8(a.cuda(), w.cuda(), bias=bias.cuda(), alpha=alpha.cuda(), beta=0.5, out_dtype=torch.bfloat16)
+    np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
+
+
 def test_gemm_kn_layout_is_linear_w8a8(N):
     """[K,N] weights, raw int32 out: the linear_w8a8 contract."""
     a, b = rand_i8((70, 96), 5), rand_i8((96, 200), 6)
@@ -265,7 +281,10 @@ def test_conv_resnet_layer_vs_torch(N):
     assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", [(2, 3, 8, 8, 5, 3, 1, 1), (2, 16, 9, 9, 70, 3, 2, 1), (2, 8, 7, 7, 12, 3, 1, 1)])
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", [(2, 3, 8, 8, 5, 3, 1, 1), (2, 16, 9, 9, 70, 3, 2, 1), (2, 8, 7, 7, 12, 3, 1, 1),
+                                              # Ho*Wo % 8 == 0: paired 16-byte bf16 stores (ragged channels / pixels)
+                                              (3, 16, 16, 16, 70, 3, 1, 1), (1, 8, 8, 12, 16, 3, 1, 1),
+                                              (5, 32, 12, 12, 200, 3, 1, 1), (2, 4, 18, 18, 9, 3, 2, 0)])
 def test_conv_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p):
     x, w = rand_i8((B, C, H, W), 9), rand_i8((Co, C, k, k), 10)
     g = torch.Generator().manual_seed(4)
