@@ -30,11 +30,23 @@ struct ConvGeom {
     int64_t B, Cin, H, W, Cout, KH, KW, stride, pad;
     int64_t Ho, Wo, Hp, Wp, Cp, L, Lp, Kp, M;
     int64_t xp_bytes, wp_bytes;
+    // 3 x 3 / stride 1 layers (conv3x3_planar_kernel): chunk-plane layout of the padded copy
+    bool planar;
+    int64_t pitch;   // pixels per padded row (Wp rounded up to 4)
+    int64_t ptot;    // flat padded pixels B * Hp * pitch
 };
+
+// conv3x3_planar_kernel's tile: kTM output pixels of one image x 64 output channels per workgroup; one stage =
+// the pixel patch of a 64-channel group (4 chunk planes of kPlaneSlots 16-byte slots) + that group's weights.
+constexpr int kTM = 448;                                // 28 fragments: 4 wave rows x 7
+constexpr int kPlaneSlots = 704;                        // >= (rows a tile touches + 2) * pitch + 2
+constexpr int kPatchBytes = 4 * kPlaneSlots * kChunk;   // 44 KiB
+constexpr int kWStageBytes = 9 * 4 * 64 * kChunk;       // 36 KiB: [tap][chunk][channel][16 B]
+constexpr int kPlanarStage = kPatchBytes + kWStageBytes;
 
 bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                int64_t pad, ConvGeom& g) {
-    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
     g.Hp = H + 2 * pad;
     g.Wp = W + 2 * pad;
@@ -48,6 +60,25 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     g.M = B * g.Ho * g.Wo;
     g.xp_bytes = B * g.Hp * g.Wp * g.Cp;
     g.wp_bytes = Cout * g.Kp;
+    // The 3 x 3 / stride 1 kernel: whole 64-channel groups, four output pixels per 16-byte store, and a
+    // patch (the padded rows a tile touches, two more, two pixels) that fits the LDS planes.
+    g.pitch = round_up(g.Wp, 4);
+    g.ptot = B * g.Hp * g.pitch;
+    const char* sw = getenv("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
+    g.planar = false;
+    if (KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
+        !(sw && sw[0] == '0')) {
+        int64_t rows = 0;
+        for (int64_t p0 = 0; p0 < g.Ho * g.Wo; p0 += kTM) {
+            const int64_t p1 = std::min<int64_t>(p0 + kTM, g.Ho * g.Wo) - 1;
+            rows = std::max(rows, p1 / g.Wo - p0 / g.Wo + 3);
+        }
+        g.planar = rows * g.pitch + 2 <= kPlaneSlots;
+    }
+    if (g.planar) {
+        g.xp_bytes = g.ptot * Cin;
+        g.wp_bytes = ceil_div(Cout, 64) * (Cin / 64) * kWStageBytes;
+    }
     return true;
 }
 
@@ -100,10 +131,13 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint3
 // 4 KiB LDS tile laid out [pixel][channel] so that each thread can store 16 channel bytes of one
 // pixel.  The 16-byte groups of a tile row are XOR-ed with the pixel's dword index to spread the
 // writes over the banks.  The zero border is written by nhwc_border_items.
+//
+// plane_stride != 0 selects the chunk-plane layout instead: xp[c / 16][b][hp][wp][c % 16], planes
+// plane_stride bytes apart, Wp then being the row pitch in pixels (Cp is a multiple of 64 there).
 template <bool DWORD>
 __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin, int H,
                                                     int W, int Hp, int Wp, int Cp, int pad, int cblocks, int bx,
-                                                    int64_t b) {
+                                                    int64_t b, int64_t plane_stride = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 16];
     const int t = threadIdx.x;
     const int HW = H * W;
@@ -138,6 +172,7 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
         const uint4 v = *reinterpret_cast<const uint4*>(&tile[pl * 16 + ((part ^ ((pl >> 2) & 3)) << 2)]);
         const int h = p / W, w = p - h * W;
         int8_t* o = xp + ((b * Hp + h + pad) * Wp + w + pad) * Cp + c0 + part * 16;
+        if (plane_stride) o = xp + ((c0 >> 4) + part) * plane_stride + ((b * Hp + h + pad) * Wp + w + pad) * 16;
         if ((Cp & 15) == 0) {
             *reinterpret_cast<uint4*>(o) = v;
         } else {
@@ -151,7 +186,7 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
 
 // Zeros in the `pad` rows above and below and the `pad` columns left and right of every image.
 __device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                  int64_t total, int64_t first, int64_t step) {
+                                                  int64_t total, int64_t first, int64_t step, int64_t plane_stride = 0) {
     const int cdw = Cp >> 2;
     const int per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
     for (int64_t idx = first; idx < total; idx += step) {
@@ -168,7 +203,10 @@ __device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H
             hp = r + pad;
             wp = k < pad ? k : W + k;
         }
-        reinterpret_cast<uint32_t*>(xp + ((b * Hp + hp) * Wp + wp) * Cp)[dw] = 0u;
+        if (plane_stride)
+            reinterpret_cast<uint32_t*>(xp + (dw >> 2) * plane_stride + ((b * Hp + hp) * Wp + wp) * 16)[dw & 3] = 0u;
+        else
+            reinterpret_cast<uint32_t*>(xp + ((b * Hp + hp) * Wp + wp) * Cp)[dw] = 0u;
     }
 }
 
@@ -216,6 +254,25 @@ __device__ __forceinline__ void pack_conv_weight_items(const int8_t* __restrict_
     }
 }
 
+// OIHW (3 x 3) -> wp[Cout / 64][Cin / 64][tap][chunk][channel % 64][16]: per 64-output-channel tile and
+// 64-input-channel group one contiguous 36 KiB image of the LDS weight stage (zero past Cout).
+__device__ __forceinline__ void pack_conv_weight_planar_items(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
+                                                              int64_t total, int Cin, int Cout, int64_t first,
+                                                              int64_t step) {
+    const int ncg = Cin >> 6;
+    for (int64_t idx = first; idx < total; idx += step) {
+        const int byte = static_cast<int>(idx & 15);
+        const int nl = static_cast<int>((idx >> 4) & 63);
+        const int kc = static_cast<int>((idx >> 10) & 3);
+        const int64_t rest = idx >> 12;                   // (tn * ncg + cg) * 9 + tap
+        const int tap = static_cast<int>(rest % 9);
+        const int cg = static_cast<int>((rest / 9) % ncg);
+        const int64_t n = (rest / 9 / ncg) * 64 + nl;
+        const int c = cg * 64 + kc * 16 + byte;
+        wp[idx] = n < Cout ? w[(n * Cin + c) * 9 + tap] : static_cast<int8_t>(0);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
                                                                int64_t total, int Cin, int KH, int KW, int Cp, int L,
                                                                int Lp) {
@@ -241,18 +298,24 @@ struct ConvPrepArgs {
     int KH, KW, L, Lp;
     int n_interior, n_extra;
     int64_t border_total, weight_total;
+    int64_t plane_stride;   // != 0: chunk-plane layout (Wp = row pitch), weights packed for conv3x3_planar_kernel
+    int Cout;
 };
 
 template <bool DWORD>
 __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
     if (static_cast<int>(blockIdx.x) < a.n_interior) {
-        nhwc_interior_block<DWORD>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y);
+        nhwc_interior_block<DWORD>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y,
+                                   a.plane_stride);
         return;
     }
     const int64_t first = (static_cast<int64_t>(blockIdx.y) * a.n_extra + (blockIdx.x - a.n_interior)) * 256 + threadIdx.x;
     const int64_t step = static_cast<int64_t>(gridDim.y) * a.n_extra * 256;
-    nhwc_border_items(a.xp, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.border_total, first, step);
-    pack_conv_weight_items(a.w, a.wp, a.weight_total, a.Cin, a.KH, a.KW, a.Cp, a.L, a.Lp, first, step);
+    nhwc_border_items(a.xp, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.border_total, first, step, a.plane_stride);
+    if (a.plane_stride)
+        pack_conv_weight_planar_items(a.w, a.wp, a.weight_total, a.Cin, a.Cout, first, step);
+    else
+        pack_conv_weight_items(a.w, a.wp, a.weight_total, a.Cin, a.KH, a.KW, a.Cp, a.L, a.Lp, first, step);
 }
 
 struct ConvArgs {
@@ -480,6 +543,228 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3 x 3, stride 1: the convolution as nine shifted GEMMs over a pixel patch that stays in LDS.
+//
+// The padded copy is kept in chunk planes, xp[c / 16][image][padded row][padded column][c % 16], rows at a
+// pitch that is a multiple of 4 pixels.  A tile is kTM consecutive output pixels of one image (flat y * Wo +
+// x, so output stores are the same aligned 64-byte runs as the im2col-order kernel's); its patch is every
+// padded row those pixels' windows touch: per chunk plane ONE contiguous run in memory, copied by LDS-DMA as
+// it lies.  The output pixel (y, x) reads, for filter tap (kh, kw), patch pixel (y - y0 + kh) * pitch + x +
+// kw: per lane a base computed once per tile plus a shift that is the same for all lanes.  Every input byte
+// is staged once per 64-channel tile instead of nine times, and a workgroup waits for one fetch per tile
+// instead of one per 128-byte K-tile.  In LDS a fragment read takes plane lane>>4, pixel base(lane&15):
+// consecutive 16-byte slots per plane (a step of pitch - Wo where the sixteen pixels cross a row end),
+// planes a multiple of 256 bytes apart.  The weights of the 64-channel group sit beside the patch as
+// [tap][chunk][channel].
+//
+// Two persistent workgroups per CU (80 KiB of LDS, 128 registers) walk (image, tile, channel tile) units: while
+// one waits for its stage the other multiplies.  A unit's output stores are issued behind the next
+// stage's fetch and are not waited for (counted vmcnt), so they drain under the following MFMAs.
+// ---------------------------------------------------------------------------------------
+struct PlanarArgs {
+    const int8_t* xp;
+    const int8_t* wp;
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int Cout, ncg, tiles_n, tiles_img, units;
+    int pitch, Hp, Wo, HoWo;
+    uint32_t ptot;                // flat padded pixels of one chunk plane
+    uint32_t wo_magic;            // floor(2^32 / Wo) + 1
+    uint32_t xp_bytes, wp_bytes;
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 16] (the instruction takes an immediate).
+__device__ __forceinline__ void wait_vmcnt_upto16(int n) {
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+#define MIQ_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        MIQ_VMCNT_CASE(1) MIQ_VMCNT_CASE(2) MIQ_VMCNT_CASE(3) MIQ_VMCNT_CASE(4) MIQ_VMCNT_CASE(5) MIQ_VMCNT_CASE(6)
+        MIQ_VMCNT_CASE(7) MIQ_VMCNT_CASE(8) MIQ_VMCNT_CASE(9) MIQ_VMCNT_CASE(10) MIQ_VMCNT_CASE(11) MIQ_VMCNT_CASE(12)
+        MIQ_VMCNT_CASE(13) MIQ_VMCNT_CASE(14) MIQ_VMCNT_CASE(15) MIQ_VMCNT_CASE(16)
+#undef MIQ_VMCNT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int OUT, bool STREAM>
+__global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) {   // 4 waves per SIMD: two workgroups per CU
+    constexpr int FM = 7, FN = 2;   // per wave: 7 pixel fragments x 2 channel fragments; waves 4 (pixels) x 2 (channels)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+
+    struct Unit {
+        uint32_t b, p0, y0, tn;   // image, first output pixel of the tile, its row, channel tile
+    };
+    auto decode = [&](int unit) {
+        Unit u;
+        u.tn = static_cast<uint32_t>(unit % g.tiles_n);
+        const uint32_t t = static_cast<uint32_t>(unit / g.tiles_n);
+        u.b = t / g.tiles_img;
+        u.p0 = (t - u.b * g.tiles_img) * kTM;
+        u.y0 = u.p0 / g.Wo;
+        return u;
+    };
+
+    // One stage: 44 wave-instructions of patch (4 planes x 11 KiB) and 36 of weights, dealt over the waves.
+    auto issue = [&](const Unit& u, int cg, char* stage) {
+        const uint32_t first = (u.b * g.Hp + u.y0) * g.pitch;   // padded flat pixel the patch starts at
+        // (loops kept rolled: once per stage, and unrolled their wave-uniform addresses crowd the scalar registers)
+#pragma unroll 1
+        for (int q = wave; q < 44; q += 8) {
+            const int plane = q / 11, seg = q - plane * 11;
+            // behind the rows the tile needs, the run continues into later rows (or past the buffer: zeros)
+            const uint32_t off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
+            dma16(rx, stage + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
+        }
+#pragma unroll 1
+        for (int q = wave; q < 36; q += 8)
+            dma16(rw, stage + kPatchBytes + q * 1024, ((u.tn * g.ncg + cg) * 36 + q) * 1024 + lane * kChunk);
+    };
+
+    v4i acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    // Epilogue.  D[i][j]: i = 4*(lane>>4) + reg -> pixel, j = lane&15 -> output channel.  Returns the number
+    // of store instructions it issued (wave-uniform): the caller's counted vmcnt leaves exactly those in flight.
+    auto epilogue = [&](const Unit& u) -> int {
+        int issued = 0;
+        float al[FN], bi[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+            al[j] = 1.f;
+            bi[j] = 0.f;
+            if constexpr (OUT != kOutI32) {
+                if (n < g.Cout) {
+                    al[j] = g.alpha[n];
+                    if (g.bias) bi[j] = g.bias[n];
+                }
+            }
+        }
+        // (opaque to the optimiser: otherwise it keeps a loop-invariant register per fragment, and spills)
+        uint32_t pfirst = u.p0 + wm * FM * 16 + (lane >> 4) * 4;
+        asm volatile("" : "+v"(pfirst));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const uint32_t p = pfirst + i * 16;   // HoWo % 4 == 0: four pixels in or out together
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+                const v4i a = acc[i][j];
+                acc[i][j] = v4i{0, 0, 0, 0};
+                const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout;
+                if (__ballot(mine) == 0) continue;   // wave-uniform: no store instruction for this fragment
+                ++issued;
+                if (!mine) continue;
+                const size_t idx = (static_cast<size_t>(u.b) * g.Cout + n) * g.HoWo + p;
+                if constexpr (OUT == kOutI32) {
+                    v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
+                    if constexpr (STREAM) {
+                        __builtin_nontemporal_store(a, o);
+                    } else {
+                        *o = a;
+                    }
+                } else if constexpr (OUT == kOutF32) {
+                    const v4f v{dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
+                                dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta)};
+                    v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
+                    if constexpr (STREAM) {
+                        __builtin_nontemporal_store(v, o);
+                    } else {
+                        *o = v;
+                    }
+                } else {
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) =
+                        pack4_bf16(dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
+                                   dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta));
+                }
+            }
+        }
+        return issued;
+    };
+
+    const int w_lane = ((lane >> 4) * 64 + wn * 32 + (lane & 15)) * kChunk;
+
+    bool pending = false;   // the previous unit's accumulators wait to be stored
+    Unit prev{};
+    for (int unit = blockIdx.x; unit < g.units; unit += gridDim.x) {
+        const Unit u = decode(unit);
+        // patch address of each fragment row this lane supplies: plane lane>>4, pixel (y - y0) * pitch + x
+        int aoff[FM];
+        uint32_t qfirst = u.p0 + wm * FM * 16 + (lane & 15);
+        asm volatile("" : "+v"(qfirst));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            uint32_t p = qfirst + i * 16;
+            if (p >= static_cast<uint32_t>(g.HoWo)) p = g.HoWo - 1;   // rows past the image: computed, never stored
+            const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
+            aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + ((y - u.y0) * g.pitch + x) * kChunk;
+        }
+        for (int cg = 0; cg < g.ncg; ++cg) {
+            issue(u, cg, smem);
+            int stores = 0;
+            if (pending) {   // the previous unit's stores go out under this stage's fetch
+                stores = epilogue(prev);
+                pending = false;
+            }
+            // The stage has landed once all but the `stores` youngest operations are done (vector memory
+            // operations retire in issue order): the stores themselves are not waited for, so they drain
+            // under the MFMAs below instead of holding the workgroup until memory has taken them.
+            wait_vmcnt_upto16(stores);
+            __syncthreads();
+            // One filter row per iteration, kept as a loop: unrolled over all nine taps the compiler
+            // prefetches fragments across taps and spills at the 128 registers two workgroups per CU allow;
+            // four waves per SIMD hide the fragment reads instead.
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh) {
+                const char* arow = smem + kh * g.pitch * kChunk;
+                const char* wrow = smem + kPatchBytes + kh * (3 * 4096) + w_lane;
+#pragma unroll 1
+                for (int kw = 0; kw < 3; ++kw) {
+                    v4i wf[FN];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wrow + kw * 4096 + j * 256);
+#pragma unroll
+                    for (int i0 = 0; i0 < FM; i0 += 4) {   // pixel fragments in two batches: fewer live registers
+                        v4i af[4];
+#pragma unroll
+                        for (int i = i0; i < FM && i < i0 + 4; ++i) af[i - i0] = lds_read16(arow + aoff[i] + kw * kChunk);
+#pragma unroll
+                        for (int i = i0; i < FM && i < i0 + 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i - i0], wf[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();   // the stage is read: the next one may overwrite it
+        }
+        prev = u;
+        pending = true;
+    }
+    if (pending) (void)epilogue(prev);
+}
+
+template <int OUT>
+int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
+    auto kern = conv3x3_planar_kernel<OUT, false>;
+    if (stream_out) kern = conv3x3_planar_kernel<OUT, true>;
+    constexpr int kLds = kPlanarStage;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    const int grid = g.units < 512 ? g.units : 512;   // two persistent workgroups per CU
+    kern<<<grid, 512, kLds, st>>>(g);
+    return check_launch("conv3x3_planar_kernel");
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tile(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
@@ -601,7 +886,25 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         bool packed = false;   // the weight re-layout rode along with the activation re-layout
         dim3 grid(static_cast<unsigned>(miq::ceil_div(G.Wp, 64) * cblocks), static_cast<unsigned>(G.Hp),
                   static_cast<unsigned>(B));
-        if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4) {
+        if (G.planar) {
+            ConvPrepArgs pa{};
+            pa.x = x; pa.xp = xp; pa.w = w; pa.wp = wp;
+            pa.Cin = (int)Cin; pa.H = (int)H; pa.W = (int)W; pa.Hp = (int)G.Hp; pa.Wp = (int)G.pitch; pa.Cp = (int)Cin;
+            pa.pad = (int)pad; pa.cblocks = (int)(Cin / 64);
+            pa.plane_stride = G.ptot * kChunk;
+            pa.Cout = (int)Cout;
+            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
+            pa.border_total = B * (2 * pad * G.pitch + 2 * pad * H) * (Cin / 4);
+            pa.weight_total = G.wp_bytes;
+            const int64_t extra = miq::ceil_div(pa.border_total + pa.weight_total, 1024);
+            pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
+            dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
+            if ((H * W) % 4 == 0 && miq::aligned(x, 4))
+                conv_prep_kernel<true><<<pgrid, 256, 0, st>>>(pa);
+            else
+                conv_prep_kernel<false><<<pgrid, 256, 0, st>>>(pa);
+            packed = true;
+        } else if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4) {
             const int64_t total4 = B * G.Hp * (W / 4);
             const int g4 = static_cast<int>(total4 / 256 + 1 < (1 << 20) ? total4 / 256 + 1 : (1 << 20));
             nhwc_pad_c4_kernel<<<g4, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)pad, total4);
@@ -634,6 +937,30 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
                                                            (int)G.Lp);
             if (int rc = miq::check_launch("pack_conv_weight_kernel")) return rc;
+        }
+    }
+
+    if (G.planar) {
+        PlanarArgs pa{};
+        pa.xp = xp; pa.wp = wp; pa.bias = bias; pa.alpha = alpha; pa.out = out; pa.beta = beta;
+        pa.Cout = (int)Cout; pa.ncg = (int)(Cin / 64); pa.tiles_n = (int)miq::ceil_div(Cout, 64);
+        pa.tiles_img = (int)miq::ceil_div(G.Ho * G.Wo, kTM);
+        pa.pitch = (int)G.pitch; pa.Hp = (int)G.Hp; pa.Wo = (int)G.Wo; pa.HoWo = (int)(G.Ho * G.Wo);
+        pa.ptot = (uint32_t)G.ptot;
+        pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
+        pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)G.wp_bytes;
+        const int64_t units = B * pa.tiles_img * pa.tiles_n;
+        MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
+        pa.units = (int)units;
+        // as below: outputs far beyond the Infinity Cache stream past it (16-byte stores only)
+        const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
+        switch (out_dtype) {
+            case MIQ_F32:
+                return launch_planar<kOutF32>(pa, stream_out, st);
+            case MIQ_BF16:
+                return launch_planar<kOutBF16>(pa, stream_out, st);
+            default:
+                return launch_planar<kOutI32>(pa, stream_out, st);
         }
     }
 
