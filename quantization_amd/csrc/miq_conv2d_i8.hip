@@ -73,7 +73,9 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
             const int64_t p1 = std::min<int64_t>(p0 + kTM, g.Ho * g.Wo) - 1;
             rows = std::max(rows, p1 / g.Wo - p0 / g.Wo + 3);
         }
-        g.planar = rows * g.pitch + 2 <= kPlaneSlots;
+        // ... and tiles that are mostly pixels: an image smaller than a tile would leave its fragments empty
+        const int64_t tiles_img = ceil_div(g.Ho * g.Wo, kTM);
+        g.planar = rows * g.pitch + 2 <= kPlaneSlots && 5 * g.Ho * g.Wo >= 4 * tiles_img * kTM;
     }
     if (g.planar) {
         g.xp_bytes = g.ptot * Cin;
@@ -574,6 +576,7 @@ struct PlanarArgs {
     uint32_t ptot;                // flat padded pixels of one chunk plane
     uint32_t wo_magic;            // floor(2^32 / Wo) + 1
     uint32_t xp_bytes, wp_bytes;
+    int wide16;                   // bf16 output: paired 16-byte stores (HoWo % 8 == 0, 16-byte aligned output)
 };
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 16] (the instruction takes an immediate).
@@ -653,8 +656,41 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
         // (opaque to the optimiser: otherwise it keeps a loop-invariant register per fragment, and spills)
         uint32_t pfirst = u.p0 + wm * FM * 16 + (lane >> 4) * 4;
         asm volatile("" : "+v"(pfirst));
+        constexpr int kPaired = OUT == kOutBF16 ? FM / 2 * 2 : 0;   // bf16: fragments (0,1), (2,3), (4,5) go out paired
+        if constexpr (OUT == kOutBF16) {
+            // as in the im2col-order kernel: two neighbouring pixel fragments trade 16-lane rows, and a lane
+            // stores eight consecutive pixels of its channel as one 16-byte vector
+            if (g.wide16) {
+                uint32_t ppair = u.p0 + wm * FM * 16 + paired_offset(lane);
+                asm volatile("" : "+v"(ppair));
+#pragma unroll
+                for (int i = 0; i < kPaired; i += 2) {
+                    const uint32_t p = ppair + i * 16;   // HoWo % 8 == 0: eight pixels in or out together
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+                        uint2 h[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const v4i a = acc[i + e][j];
+                            acc[i + e][j] = v4i{0, 0, 0, 0};
+                            h[e] = pack4_bf16(dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
+                                              dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta));
+                        }
+                        const v4i v = pair_rows_bf16(h[0], h[1]);
+                        const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout;
+                        if (__ballot(mine) == 0) continue;
+                        ++issued;
+                        if (mine)
+                            *reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) +
+                                                    (static_cast<size_t>(u.b) * g.Cout + n) * g.HoWo + p) = v;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
+            if (OUT == kOutBF16 && i < kPaired && g.wide16) continue;   // stored above
             const uint32_t p = pfirst + i * 16;   // HoWo % 4 == 0: four pixels in or out together
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -728,22 +764,19 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
             for (int kh = 0; kh < 3; ++kh) {
                 const char* arow = smem + kh * g.pitch * kChunk;
                 const char* wrow = smem + kPatchBytes + kh * (3 * 4096) + w_lane;
-#pragma unroll 1
+#pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     v4i wf[FN];
 #pragma unroll
                     for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wrow + kw * 4096 + j * 256);
+                    v4i af[FM];
 #pragma unroll
-                    for (int i0 = 0; i0 < FM; i0 += 4) {   // pixel fragments in two batches: fewer live registers
-                        v4i af[4];
+                    for (int i = 0; i < FM; ++i) af[i] = lds_read16(arow + aoff[i] + kw * kChunk);
 #pragma unroll
-                        for (int i = i0; i < FM && i < i0 + 4; ++i) af[i - i0] = lds_read16(arow + aoff[i] + kw * kChunk);
+                    for (int i = 0; i < FM; ++i)
 #pragma unroll
-                        for (int i = i0; i < FM && i < i0 + 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < FN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i - i0], wf[j], acc[i][j], 0, 0, 0);
-                    }
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
                 }
             }
             __syncthreads();   // the stage is read: the next one may overwrite it
@@ -949,6 +982,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         pa.ptot = (uint32_t)G.ptot;
         pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
         pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)G.wp_bytes;
+        pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
         const int64_t units = B * pa.tiles_img * pa.tiles_n;
         MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
         pa.units = (int)units;
