@@ -907,6 +907,10 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             case 'j': return launch_tile<128, 64, 4, 2, OUT, 3>(g, st);
             case 'k': return launch_tile<64, 128, 2, 2, OUT, 3>(g, st);
             case 'l': return launch_tile<64, 64, 2, 2, OUT, 4>(g, st);
+            case 'm': return launch_tile<128, 128, 2, 2, OUT, 3>(g, st);
+            case 'n': return launch_tile<128, 128, 2, 4, OUT, 4>(g, st);
+            case 'o': return launch_tile<128, 128, 2, 4, OUT, 3>(g, st);
+            case 'p': return launch_tile<128, 256, 2, 4, OUT, 3>(g, st);
             default: break;
         }
     }
@@ -917,6 +921,15 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     }
     // 128 x 128: double-buffered (two workgroups per CU at 64 KiB each beat one with a 96 KiB ring: 18 vs 24 us
     // at M = 128 on [14336, 4096]); 64- and 32-row tiles: four-deep ring (12-14 vs 18-20 us unsplit).
+    if (plan.bm == 128 && plan.splits == 1 && !(stg && stg[0] == '2')) {
+        // Every tile resident at once (one workgroup per CU): nothing to gain from a second workgroup per CU,
+        // so the LDS goes to a three-deep ring and the tile to eight waves (measured: 24.9 vs 30.4 us at
+        // 256 x 14336 x 4096, 25.7 vs 29.8 us at 1024 x 4096 x 4096); with a deep K the same holds for
+        // 128 x 256 tiles when those fit one round (67.8 vs 82.2 us at 256 x 28672 x 8192; no gain at K = 4096).
+        const int64_t t128 = ceil_div(g.M, 128) * ceil_div(g.N, 128), t256 = ceil_div(g.M, 128) * ceil_div(g.N, 256);
+        if (t128 <= 256) return launch_tile<128, 128, 2, 4, OUT, 3>(g, st);
+        if (t256 <= 256 && g.K >= 8192) return launch_tile<128, 256, 2, 4, OUT, 3>(g, st);
+    }
     if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
