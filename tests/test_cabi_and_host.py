@@ -55,8 +55,10 @@ def test_argument_validation_needs_no_device():
     assert lib.miq_gemm_i8_workspace(1, 8, 100, 64) == 6400 and lib.miq_gemm_i8_workspace(0, 8, 100, 64) == 0
     assert lib.miq_conv2d_i8(ctypes.c_void_p(64), ctypes.c_void_p(64), 1, 3, 2, 2, 4, 3, 3, 1, 0, null, null, 0.0,
                              ctypes.c_void_p(64), 3, null, 0, null) == -1   # kernel larger than the input
-    # 256 x (58*58*64) padded activations + 64 x (3*192) packed weights, each rounded to 256 B
-    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 64, 3, 3, 1, 1) == 256 * 58 * 58 * 64 + 64 * 576
+    # 3 x 3 / stride 1 (chunk-plane copy): 256 x (58 rows x pitch 60 x 64 channels) + one 36 KiB weight stage
+    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 64, 3, 3, 1, 1) == 256 * 58 * 60 * 64 + 9 * 4 * 64 * 16
+    # any other layer: 256 x (58*58*64) padded channels-last activations + 128 x (3*192) packed weights
+    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 128, 3, 3, 2, 1) == 256 * 58 * 58 * 64 + 128 * 576
     # zero-sized problems succeed without touching a device
     assert lib.miq_gemm_i8(null, null, 0, 0, 8, 16, null, null, 0.0, null, 3, null, 0, null) == 0
     assert lib.miq_quantize_rows_sym_i8(null, 0, 0, 16, null, null, null, null, null) == 0
