@@ -255,6 +255,15 @@ def main():
                 },
             },
         }
+        if world > 1:
+            # what the step is bound by at N > 1: every rank receives the other ranks' fp32 blocks over xGMI
+            recv = (world - 1) * M * S * 4
+            line["extra"]["allgather"] = {
+                "bytes_received_per_gpu_per_step": recv,
+                "GBps_per_gpu_if_step_were_only_the_gather": round(recv / (ms_per_step * 1e-3) / 1e9, 1),
+                "gemm_kernel_ms": round(k_ms, 4),
+                "note": "the all-gather of step i overlaps the GEMM of step i+1; a step costs max(gather, GEMM)",
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)
