@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "miq.h"
 
@@ -13,6 +14,19 @@ namespace miq {
 // Thread-local message behind miq_last_error().
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
+
+// Developer A/B switches (tile shapes, kernel variants, timing-only builds: what tools/*_ab.py and the
+// ablation tables under profiles/ are made with) are environment variables read per call through this one
+// function.  They choose between kernels that all compute the same result; a build with
+// -DMIQ_NO_DEV_SWITCHES ignores them all.
+inline const char* dev_switch(const char* name) {
+#ifdef MIQ_NO_DEV_SWITCHES
+    (void)name;
+    return nullptr;
+#else
+    return getenv(name);
+#endif
+}
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

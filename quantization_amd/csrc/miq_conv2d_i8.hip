@@ -64,7 +64,7 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     // patch (the padded rows a tile touches, two more, two pixels) that fits the LDS planes.
     g.pitch = round_up(g.Wp, 4);
     g.ptot = B * g.Hp * g.pitch;
-    const char* sw = getenv("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
+    const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
     g.planar = false;
     if (KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
         !(sw && sw[0] == '0')) {
@@ -814,7 +814,7 @@ template <int OUT>
 int launch(const ConvArgs& g, hipStream_t st) {
     // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
     auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
-    if (const char* force = getenv("MIQ_CONV_TILE")) {   // developer A/B switch
+    if (const char* force = dev_switch("MIQ_CONV_TILE")) {   // developer A/B switch
         switch (force[0]) {
             case 'a': return launch_tile<256, 256, 2, 4, OUT>(g, st);
             case 'b': return launch_tile<256, 128, 2, 4, OUT>(g, st);

@@ -786,13 +786,13 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
     if (M > 128 && big_tiles >= 192) return p;
     if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
-        const char* sk = getenv("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
+        const char* sk = dev_switch("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
         if (!(sk && sk[0] == '0')) {
             p.bm = 0;
             return p;
         }
     }
-    const char* mid = getenv("MIQ_GEMM_MID");   // developer A/B switch: largest M that takes 64-row tiles
+    const char* mid = dev_switch("MIQ_GEMM_MID");   // developer A/B switch: largest M that takes 64-row tiles
     const int64_t mid_m = mid ? atoll(mid) : 128;
     if (M > mid_m) {
         p.bm = 128; p.bn = 128;
@@ -859,14 +859,14 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     const GemmPlan plan = plan_gemm(g.M, g.N, g.K);
     if (plan.bm == 0) return launch_skinny<1, OUT>(g, st);
     if (plan.bm == 256) {
-        const char* simple = getenv("MIQ_GEMM_SIMPLE");   // developer A/B switch
+        const char* simple = dev_switch("MIQ_GEMM_SIMPLE");   // developer A/B switch
         if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
         g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
         g.tiles_n = static_cast<int>(ceil_div(g.N, 256));
         constexpr int kLds = 2 * 4 * 128 * kTileK;
-        const char* var = getenv("MIQ_GEMM_VARIANT");     // developer A/B switch
+        const char* var = dev_switch("MIQ_GEMM_VARIANT");     // developer A/B switch
         auto kern = (var && var[0] == '0') ? gemm_i8_256_kernel<OUT, 0> : gemm_i8_256_kernel<OUT, 2>;
-        const char* abl = getenv("MIQ_GEMM_ABL");
+        const char* abl = dev_switch("MIQ_GEMM_ABL");
         if (abl && abl[0] == 'n') kern = gemm_i8_256_kernel<OUT, 2, 256>;   // plain (cached) epilogue stores
         if (abl && abl[0] == 'h') kern = gemm_i8_256_kernel<OUT, 2, 512>;   // bf16: 8-byte stores, fragments unpaired
         if (abl && abl[0] == 'H') kern = gemm_i8_256_kernel<OUT, 2, 512 + 256>;
@@ -881,7 +881,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             if (abl[0] == 'c') kern = gemm_i8_256_kernel<OUT, 0, 32 + 2>;
             if (abl[0] == 's') {   // segment stamps into the buffer whose address MIQ_GEMM_STAMPS holds (hex)
                 kern = gemm_i8_256_kernel<OUT, 0, 64>;
-                const char* sp = getenv("MIQ_GEMM_STAMPS");
+                const char* sp = dev_switch("MIQ_GEMM_STAMPS");
                 g.stamps = sp ? reinterpret_cast<unsigned*>(strtoull(sp, nullptr, 16)) : nullptr;
             }
             if (abl[0] == '3') kern = gemm_i8_256_kernel<OUT, 0, 3>;
@@ -893,7 +893,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
         return check_launch("gemm_i8_256_kernel");
     }
-    if (const char* force = getenv("MIQ_GEMM_TILE")) {   // developer A/B switch
+    if (const char* force = dev_switch("MIQ_GEMM_TILE")) {   // developer A/B switch
         switch (force[0]) {
             case 'a': return launch_tile<128, 128, 2, 2, OUT>(g, st);
             case 'b': return launch_tile<128, 64, 2, 2, OUT>(g, st);
@@ -914,7 +914,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             default: break;
         }
     }
-    const char* stg = getenv("MIQ_GEMM_STAGES");   // developer A/B switch: 2 = double-buffered kernels
+    const char* stg = dev_switch("MIQ_GEMM_STAGES");   // developer A/B switch: 2 = double-buffered kernels
     if (stg && stg[0] == '2') {
         if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
         if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);

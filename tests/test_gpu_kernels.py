@@ -279,6 +279,22 @@ def test_conv_i32_bit_exact(N, B, C, H, W, Co, k, s, p):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+def test_conv_3x3_random_shapes_vs_torch(N):
+    """Seeded random 3 x 3 / stride 1 layers with whole 64-channel groups (most take the LDS-resident-patch
+    kernel, the small ones the im2col-order kernel) against F.conv2d in float64, exact on these integers."""
+    rng = np.random.default_rng(2024)
+    for _ in range(16):
+        C = 64 * int(rng.integers(1, 4))
+        H, W = int(rng.integers(6, 61)), int(rng.integers(6, 61))
+        pad = int(rng.integers(0, 3))
+        Co = int(rng.integers(1, 140))
+        B = int(rng.integers(1, 4)) + 2200 // ((H + 2 * pad - 2) * (W + 2 * pad - 2))
+        x, w = rand_i8((B, C, H, W), B + H), rand_i8((Co, C, 3, 3), Co + W)
+        ref = torch.nn.functional.conv2d(x.cuda().double(), w.cuda().double(), stride=1, padding=pad).to(torch.int32)
+        out = N.conv2d_i8(x.cuda(), w.cuda(), 1, pad, out_dtype=torch.int32)
+        assert torch.equal(out, ref), (B, C, H, W, Co, pad)
+
+
 def test_conv_resnet_layer_vs_torch(N):
     """A ResNet-18 layer1 shape at a small batch, checked against F.conv2d in float64."""
     x, w = rand_i8((4, 64, 56, 56), 1), rand_i8((64, 64, 3, 3), 2)
