@@ -779,10 +779,11 @@ struct GemmPlan {
     int bn;
     int splits;  // 1 = no split
     int kt_per_split;
+    bool ring;   // 128-row tiles: eight-wave three-deep ring kernel (every workgroup resident at once)
 };
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
-    GemmPlan p{256, 256, 1, 0};
+    GemmPlan p{256, 256, 1, 0, false};
     const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
     if (M > 128 && big_tiles >= 192) return p;
     if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
@@ -812,6 +813,15 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
         if (splits > K / (8 * M)) splits = K / (8 * M);      // slab traffic (2 * 4*splits*M*N) <= weight bytes N*K
         if (splits > 32) splits = 32;
         if (splits < 1) splits = 1;
+    }
+    // 128-row tiles: cut so that all slices are resident at once, one workgroup per CU, and run on the
+    // eight-wave ring kernel (measured against ~2 double-buffered workgroups per CU: 29.8 vs 31.8 us at
+    // 256 x 4096 x 14336, 74.2 vs 88.2 us at 256 x 8192 x 28672, 18.7 vs 21.2 us at 256 x 4096 x 4096)
+    const char* sr = dev_switch("MIQ_GEMM_SPLIT_RING");   // developer A/B switch: 0 = double-buffered slices
+    if (p.bm == 128 && splits > 1 && !(sr && sr[0] == '0') && tiles * 2 <= 256) {
+        splits = 256 / tiles;
+        if (splits > nt / 8) splits = nt / 8;
+        p.ring = true;
     }
     if (splits > 1) {
         p.kt_per_split = static_cast<int>(ceil_div(nt, splits));
@@ -930,6 +940,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         if (t128 <= 256) return launch_tile<128, 128, 2, 4, OUT, 3>(g, st);
         if (t256 <= 256 && g.K >= 8192) return launch_tile<128, 256, 2, 4, OUT, 3>(g, st);
     }
+    if (plan.bm == 128 && plan.ring) return launch_tile<128, 128, 2, 4, OUT, 3>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 32) return launch_tile<32, 64, 1, 4, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);
