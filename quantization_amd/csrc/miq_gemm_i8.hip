@@ -785,7 +785,9 @@ struct GemmPlan {
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     GemmPlan p{256, 256, 1, 0, false};
     const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
-    if (M > 128 && big_tiles >= 192) return p;
+    // (a weight narrower than 3/4 of its 256-column tiles would leave the tile's columns empty)
+    const bool wide_enough = 4 * N >= 3 * ceil_div(N, 256) * 256;
+    if (M > 128 && big_tiles >= 192 && wide_enough) return p;
     if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
         const char* sk = dev_switch("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
         if (!(sk && sk[0] == '0')) {
@@ -796,7 +798,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const char* mid = dev_switch("MIQ_GEMM_MID");   // developer A/B switch: largest M that takes 64-row tiles
     const int64_t mid_m = mid ? atoll(mid) : 128;
     if (M > mid_m) {
-        p.bm = 128; p.bn = 128;
+        p.bm = 128; p.bn = N <= 64 ? 64 : 128;   // 137.7 vs 151.7 us at 802816 x 64 x 576
     } else if (M > 32) {
         p.bm = 64; p.bn = 64;
     } else if (M > 16) {
@@ -818,7 +820,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     // eight-wave ring kernel (measured against ~2 double-buffered workgroups per CU: 29.8 vs 31.8 us at
     // 256 x 4096 x 14336, 74.2 vs 88.2 us at 256 x 8192 x 28672, 18.7 vs 21.2 us at 256 x 4096 x 4096)
     const char* sr = dev_switch("MIQ_GEMM_SPLIT_RING");   // developer A/B switch: 0 = double-buffered slices
-    if (p.bm == 128 && splits > 1 && !(sr && sr[0] == '0') && tiles * 2 <= 256) {
+    if (p.bm == 128 && p.bn == 128 && splits > 1 && !(sr && sr[0] == '0') && tiles * 2 <= 256) {
         splits = 256 / tiles;
         if (splits > nt / 8) splits = nt / 8;
         p.ring = true;
@@ -931,7 +933,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     }
     // 128 x 128: double-buffered (two workgroups per CU at 64 KiB each beat one with a 96 KiB ring: 18 vs 24 us
     // at M = 128 on [14336, 4096]); 64- and 32-row tiles: four-deep ring (12-14 vs 18-20 us unsplit).
-    if (plan.bm == 128 && plan.splits == 1 && !(stg && stg[0] == '2')) {
+    if (plan.bm == 128 && plan.bn == 128 && plan.splits == 1 && !(stg && stg[0] == '2')) {
         // Every tile resident at once (one workgroup per CU): nothing to gain from a second workgroup per CU,
         // so the LDS goes to a three-deep ring and the tile to eight waves (measured: 24.9 vs 30.4 us at
         // 256 x 14336 x 4096, 25.7 vs 29.8 us at 1024 x 4096 x 4096); with a deep K the same holds for
@@ -940,6 +942,7 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
         if (t128 <= 256) return launch_tile<128, 128, 2, 4, OUT, 3>(g, st);
         if (t256 <= 256 && g.K >= 8192) return launch_tile<128, 256, 2, 4, OUT, 3>(g, st);
     }
+    if (plan.bm == 128 && plan.bn == 64) return launch_tile<128, 64, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 128 && plan.ring) return launch_tile<128, 128, 2, 4, OUT, 3>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 128) return launch_tile<128, 128, 2, 2, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
     if (plan.bm == 64) return launch_tile<64, 64, 2, 2, OUT, 4>(g, st, plan.splits, plan.kt_per_split, slabs);

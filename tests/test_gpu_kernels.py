@@ -134,6 +134,8 @@ GEMM_SHAPES = [
     (128, 128, 128), (129, 257, 400), (200, 520, 384), (256, 256, 256), (300, 4096, 256), (512, 768, 1024),
     (1024, 4096, 2048),  # the reference's own test shape (linear_int8/test.py:5-6)
     (37, 130, 300), (3, 4, 6), (5, 48, 64),  # K not a multiple of 16 -> element-wise kernel
+    # narrow weights with many rows: kept off the 256-column tiles (128 x 64 tiles up to 64 channels)
+    (60000, 64, 64), (50000, 100, 48), (200, 40, 4096), (50000, 200, 32),
     # thin problems: split along K into int32 slabs + reduce kernel
     (1, 256, 4096), (16, 1024, 14336), (40, 520, 8192), (100, 300, 2064), (256, 512, 8192), (200, 128, 16384),
 ]
