@@ -790,7 +790,11 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     if (M > 128 && big_tiles >= 192 && wide_enough) return p;
     if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
         const char* sk = dev_switch("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
-        if (!(sk && sk[0] == '0')) {
+        // ... unless the weight has enough 64-channel tiles to fill the chip without split-K: the 32-row ring
+        // kernel then streams it faster (15.7-16.6 vs 17.0-19.2 us on [14336,4096]; with split-K it loses,
+        // 21-22 vs 16-18 us on [4096,14336])
+        const bool wide = ceil_div(N, 64) >= 160 && !(sk && sk[0] == '1');
+        if (!(sk && sk[0] == '0') && !wide) {
             p.bm = 0;
             return p;
         }
@@ -801,7 +805,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
         p.bm = 128; p.bn = N <= 64 ? 64 : 128;   // 137.7 vs 151.7 us at 802816 x 64 x 576
     } else if (M > 32) {
         p.bm = 64; p.bn = 64;
-    } else if (M > 16) {
+    } else if (M > 16 || ceil_div(N, 64) >= 160) {
         p.bm = 32; p.bn = 64;
     } else {
         p.bm = 16; p.bn = 64;
