@@ -186,29 +186,31 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
     }
 }
 
-// Zeros in the `pad` rows above and below and the `pad` columns left and right of every image.
+// Zeros in the `pad` rows above and below and the `pad` columns left and right of every image: one item per
+// border pixel (all of its channel bytes), 32-bit index arithmetic (64-bit divisions are an order dearer).
 __device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                  int64_t total, int64_t first, int64_t step, int64_t plane_stride = 0) {
-    const int cdw = Cp >> 2;
-    const int per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
-    for (int64_t idx = first; idx < total; idx += step) {
-        const int dw = static_cast<int>(idx % cdw);
-        const int e = static_cast<int>((idx / cdw) % per_image);
-        const int64_t b = idx / (static_cast<int64_t>(cdw) * per_image);
-        int hp, wp;
-        if (e < 2 * pad * Wp) {          // full rows: the first `pad` and the last `pad`
-            const int r = e / Wp;
-            hp = r < pad ? r : H + r;
+                                                  uint32_t total, uint32_t first, uint32_t step, int64_t plane_stride = 0) {
+    const uint32_t per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
+    for (uint32_t idx = first; idx < total; idx += step) {
+        const uint32_t b = idx / per_image, e = idx - b * per_image;
+        uint32_t hp, wp;
+        if (e < static_cast<uint32_t>(2 * pad * Wp)) {   // full rows: the first `pad` and the last `pad`
+            const uint32_t r = e / Wp;
+            hp = r < static_cast<uint32_t>(pad) ? r : H + r;
             wp = e - r * Wp;
-        } else {                         // side columns of the H interior rows
-            const int s = e - 2 * pad * Wp, r = s / (2 * pad), k = s - r * 2 * pad;
+        } else {                                         // side columns of the H interior rows
+            const uint32_t s = e - 2 * pad * Wp, r = s / (2 * pad), k = s - r * 2 * pad;
             hp = r + pad;
-            wp = k < pad ? k : W + k;
+            wp = k < static_cast<uint32_t>(pad) ? k : W + k;
         }
-        if (plane_stride)
-            reinterpret_cast<uint32_t*>(xp + (dw >> 2) * plane_stride + ((b * Hp + hp) * Wp + wp) * 16)[dw & 3] = 0u;
-        else
-            reinterpret_cast<uint32_t*>(xp + ((b * Hp + hp) * Wp + wp) * Cp)[dw] = 0u;
+        const int64_t pix = (static_cast<int64_t>(b) * Hp + hp) * Wp + wp;
+        if (plane_stride) {
+            for (int c = 0; c < (Cp >> 4); ++c) *reinterpret_cast<uint4*>(xp + c * plane_stride + pix * 16) = uint4{0u, 0u, 0u, 0u};
+        } else if ((Cp & 15) == 0) {
+            for (int c = 0; c < (Cp >> 4); ++c) reinterpret_cast<uint4*>(xp + pix * Cp)[c] = uint4{0u, 0u, 0u, 0u};
+        } else {
+            for (int c = 0; c < (Cp >> 2); ++c) reinterpret_cast<uint32_t*>(xp + pix * Cp)[c] = 0u;
+        }
     }
 }
 
@@ -239,46 +241,53 @@ __global__ __launch_bounds__(256) void nhwc_pad_c4_kernel(const int8_t* __restri
     }
 }
 
-// OIHW -> wp[Cout][KH][Lp] with (kw, c) order inside a filter row and zero fill.
+__device__ __forceinline__ uint32_t gather4_channels(const int8_t* __restrict__ w, int64_t at, int taps, int valid) {
+    uint32_t v = 0u;   // w[at], w[at + taps], ...: the same tap of `valid` consecutive input channels
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < valid) v |= static_cast<uint32_t>(static_cast<uint8_t>(w[at + static_cast<int64_t>(j) * taps])) << (8 * j);
+    return v;
+}
+
+// OIHW -> wp[Cout][KH][Lp] with (kw, c) order inside a filter row and zero fill.  One item per output dword:
+// four consecutive input channels of one tap (Cp is a multiple of 4, so they share the tap).
 __device__ __forceinline__ void pack_conv_weight_items(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
-                                                       int64_t total, int Cin, int KH, int KW, int Cp, int L, int Lp,
-                                                       int64_t first, int64_t step) {
-    for (int64_t idx = first; idx < total; idx += step) {
-        const int l = static_cast<int>(idx % Lp);
-        const int kh = static_cast<int>((idx / Lp) % KH);
-        const int64_t n = idx / (static_cast<int64_t>(Lp) * KH);
-        int8_t v = 0;
-        if (l < L) {
-            const int kw = l / Cp, c = l % Cp;
-            if (c < Cin) v = w[((n * Cin + c) * KH + kh) * KW + kw];
+                                                       uint32_t total_dwords, int Cin, int KH, int KW, int Cp, int L, int Lp,
+                                                       uint32_t first, uint32_t step) {
+    const uint32_t lp4 = Lp >> 2;
+    for (uint32_t idx = first; idx < total_dwords; idx += step) {
+        const uint32_t row = idx / lp4, l = (idx - row * lp4) * 4;   // row = n * KH + kh
+        const uint32_t n = row / KH, kh = row - n * KH;
+        uint32_t v = 0u;
+        if (l < static_cast<uint32_t>(L)) {
+            const uint32_t kw = l / Cp, c = l - kw * Cp;
+            if (c < static_cast<uint32_t>(Cin))
+                v = gather4_channels(w, ((static_cast<int64_t>(n) * Cin + c) * KH + kh) * KW + kw, KH * KW, Cin - static_cast<int>(c));
         }
-        wp[idx] = v;
+        reinterpret_cast<uint32_t*>(wp)[idx] = v;
     }
 }
 
 // OIHW (3 x 3) -> wp[Cout / 64][Cin / 64][tap][chunk][channel % 64][16]: per 64-output-channel tile and
 // 64-input-channel group one contiguous 36 KiB image of the LDS weight stage (zero past Cout).
 __device__ __forceinline__ void pack_conv_weight_planar_items(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
-                                                              int64_t total, int Cin, int Cout, int64_t first,
-                                                              int64_t step) {
-    const int ncg = Cin >> 6;
-    for (int64_t idx = first; idx < total; idx += step) {
-        const int byte = static_cast<int>(idx & 15);
-        const int nl = static_cast<int>((idx >> 4) & 63);
-        const int kc = static_cast<int>((idx >> 10) & 3);
-        const int64_t rest = idx >> 12;                   // (tn * ncg + cg) * 9 + tap
-        const int tap = static_cast<int>(rest % 9);
-        const int cg = static_cast<int>((rest / 9) % ncg);
-        const int64_t n = (rest / 9 / ncg) * 64 + nl;
-        const int c = cg * 64 + kc * 16 + byte;
-        wp[idx] = n < Cout ? w[(n * Cin + c) * 9 + tap] : static_cast<int8_t>(0);
+                                                              uint32_t total_dwords, int Cin, int Cout, uint32_t first,
+                                                              uint32_t step) {
+    const uint32_t ncg = Cin >> 6;
+    for (uint32_t idx = first; idx < total_dwords; idx += step) {
+        const uint32_t byte = (idx & 3) * 4, nl = (idx >> 2) & 63, kc = (idx >> 8) & 3;
+        const uint32_t rest = idx >> 10;                   // (tn * ncg + cg) * 9 + tap
+        const uint32_t tap = rest % 9, grp = rest / 9, cg = grp % ncg, n = (grp / ncg) * 64 + nl;
+        const uint32_t c = cg * 64 + kc * 16 + byte;
+        reinterpret_cast<uint32_t*>(wp)[idx] =
+            n < static_cast<uint32_t>(Cout) ? gather4_channels(w, (static_cast<int64_t>(n) * Cin + c) * 9 + tap, 9, 4) : 0u;
     }
 }
 
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
-                                                               int64_t total, int Cin, int KH, int KW, int Cp, int L,
+                                                               uint32_t total_dwords, int Cin, int KH, int KW, int Cp, int L,
                                                                int Lp) {
-    pack_conv_weight_items(w, wp, total, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256ll + threadIdx.x, 256ll * gridDim.x);
+    pack_conv_weight_items(w, wp, total_dwords, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256u + threadIdx.x, 256u * gridDim.x);
 }
 
 template <bool DWORD>
@@ -299,7 +308,7 @@ struct ConvPrepArgs {
     int Cin, H, W, Hp, Wp, Cp, pad, cblocks;
     int KH, KW, L, Lp;
     int n_interior, n_extra;
-    int64_t border_total, weight_total;
+    uint32_t border_total, weight_total;   // border pixels of all images; dwords of packed weights
     int64_t plane_stride;   // != 0: chunk-plane layout (Wp = row pitch), weights packed for conv3x3_planar_kernel
     int Cout;
 };
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
                                    a.plane_stride);
         return;
     }
-    const int64_t first = (static_cast<int64_t>(blockIdx.y) * a.n_extra + (blockIdx.x - a.n_interior)) * 256 + threadIdx.x;
-    const int64_t step = static_cast<int64_t>(gridDim.y) * a.n_extra * 256;
+    const uint32_t first = (blockIdx.y * a.n_extra + (blockIdx.x - a.n_interior)) * 256u + threadIdx.x;
+    const uint32_t step = gridDim.y * a.n_extra * 256u;
     nhwc_border_items(a.xp, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.border_total, first, step, a.plane_stride);
     if (a.plane_stride)
         pack_conv_weight_planar_items(a.w, a.wp, a.weight_total, a.Cin, a.Cout, first, step);
@@ -927,9 +936,9 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.plane_stride = G.ptot * kChunk;
             pa.Cout = (int)Cout;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
-            pa.border_total = B * (2 * pad * G.pitch + 2 * pad * H) * (Cin / 4);
-            pa.weight_total = G.wp_bytes;
-            const int64_t extra = miq::ceil_div(pa.border_total + pa.weight_total, 1024);
+            pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.pitch + 2 * pad * H));
+            pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if ((H * W) % 4 == 0 && miq::aligned(x, 4))
@@ -948,10 +957,10 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.pad = (int)pad; pa.cblocks = cblocks;
             pa.KH = (int)KH; pa.KW = (int)KW; pa.L = (int)G.L; pa.Lp = (int)G.Lp;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
-            pa.border_total = B * (2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 4);
-            pa.weight_total = G.wp_bytes;
-            // about four border dwords / weight bytes per extra thread, spread over the images' grid rows
-            const int64_t extra = miq::ceil_div(pa.border_total + pa.weight_total, 1024);
+            pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
+            pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+            // about four border pixels / weight dwords per extra thread, spread over the images' grid rows
+            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if ((H * W) % 4 == 0 && miq::aligned(x, 4))
@@ -965,7 +974,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         }
         if (int rc = miq::check_launch("nhwc re-layout kernel")) return rc;
         if (!packed) {
-            const int64_t total = G.wp_bytes;
+            const uint32_t total = static_cast<uint32_t>(G.wp_bytes / 4);   // dwords
             const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
             pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
                                                            (int)G.Lp);
