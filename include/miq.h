@@ -123,6 +123,26 @@ int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64
                 const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight-only Linear on floating-point activations:
+ *       out[m,n] = (sum_k x[m,k] * float(W[n,k]) + bias[n]) * alpha[n] + beta
+ *
+ * Replaces the weight-only Quantizer.forward for nn.Linear (quant/Weight_Only/Quantizer.py:79-91):
+ * `weight.to(x.dtype)` on every call, F.linear, `+ bias`, and Qop.dequantize (Qop.py:164-181) with
+ * alpha = scale, beta = 0 (zero_point is 0 for the symmetric int8 weights Qop.quantize produces).
+ * The int8 weight is read as it is stored (one byte per element) and widened in registers; the
+ * product runs on the bf16 MFMA with fp32 accumulation.  fp32 and fp16 activations are carried as
+ * two bf16 planes (hi + lo), which keeps |x - hi - lo| below 2^-17 |x| (fp16: exact), so the result
+ * agrees with the reference's fp32 product far inside 1e-3 relative; bf16 activations are used as
+ * they are.  The epilogue is evaluated in fp32 with one rounding per step.
+ * x: [M,K] row-major of x_dtype MIQ_F32 | MIQ_F16 | MIQ_BF16.  W: int8 [N,K].  bias: fp32 [N] or NULL.
+ * alpha: fp32 [N].  out: [M,N] of out_dtype MIQ_F32 | MIQ_BF16.
+ * workspace: at least miq_gemm_w8_workspace(...) bytes, 256-byte aligned (the bf16 planes of x and,
+ * for thin problems, the fp32 slabs of a split-K run); may be NULL when that size is 0. */
+size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K);
+int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
+                const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                void* workspace, size_t workspace_bytes, void* stream);
+
 /* dst[c,r] = src[r,c] for an int8 matrix src[rows, cols] (both dense).  Used to turn the
  * [K,N] weight of linear_w8a8 into the [N,K] layout once, ahead of repeated GEMMs. */
 int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream);

@@ -37,6 +37,8 @@ SYMBOLS = {
     "miq_epilogue_channels_f32": (_int, [_p, _p, _p, ctypes.c_float, _i64, _i64, _i64, _p, _p]),
     "miq_gemm_i8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_gemm_w8_workspace": (_size, [_int, _i64, _i64, _i64]),
+    "miq_gemm_w8": (_int, [_p, _int, _p, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
@@ -269,6 +271,41 @@ def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=
     ws = torch.empty(need, dtype=torch.int8, device=a.device) if need else None
     with torch.cuda.device(a.device):
         _check(L.miq_gemm_i8(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
+                             _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out
+
+
+def gemm_w8(x, w, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
+    """Weight-only Linear: out[m,n] = (sum_k x[m,k]*float(w[n,k]) + bias[n]) * alpha[n] + beta for floating-point
+    x [M,K] (fp32 / fp16 / bf16) and int8 w [N,K]."""
+    require_device(x, "input")
+    require_device(w, "weights")
+    if x.dtype not in _FLOAT_CODES or w.dtype != torch.int8:
+        raise RuntimeError(f"input must be fp32/fp16/bf16 and weights int8 (got {x.dtype}, {w.dtype})")
+    if x.dim() != 2 or w.dim() != 2:
+        raise RuntimeError("input and weights must be 2-D")
+    M, K = x.shape
+    N, Kw = w.shape
+    if K != Kw:
+        raise RuntimeError(f"shape mismatch: input is [{M},{K}], weights contract over {Kw}")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    if alpha is None:
+        raise RuntimeError("alpha (the per-channel scale) is required")
+    bias = _f32_vec(bias, N, "bias", x.device)
+    alpha = _f32_vec(alpha, N, "alpha", x.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    else:
+        require_device(out, "out")
+        if out.shape != (M, N) or out.dtype != out_dtype:
+            raise RuntimeError("out has the wrong shape or dtype")
+    L = lib()
+    code = _FLOAT_CODES[x.dtype]
+    need = L.miq_gemm_w8_workspace(code, M, N, K)
+    ws = torch.empty(need, dtype=torch.int8, device=x.device) if need else None
+    with torch.cuda.device(x.device):
+        _check(L.miq_gemm_w8(_ptr(x), code, _ptr(w), M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
                              _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
     return out
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmiq.so")
-SOURCES = ["miq_api.hip", "miq_quantize.hip", "miq_gemm_i8.hip", "miq_conv2d_i8.hip", "miq_pool.hip", "miq_activation.hip"]
+SOURCES = ["miq_api.hip", "miq_quantize.hip", "miq_gemm_i8.hip", "miq_gemm_w8f.hip", "miq_conv2d_i8.hip", "miq_pool.hip", "miq_activation.hip"]
 HEADERS = ["miq_common.h", "miq_gemm_core.h"]
 
 FLAGS = [

@@ -1,0 +1,483 @@
+// Weight-only Linear forward: floating-point activations x int8 weights on the CDNA4 bf16 MFMA
+// (v_mfma_f32_16x16x32_bf16) with the per-channel dequant epilogue fused:
+//     out[m,n] = (sum_k x[m,k] * float(W[n,k]) + bias[n]) * alpha[n] + beta.
+//
+// Replaces what quant/Weight_Only/Quantizer.py:79-91 does per forward call: `weight.to(x.dtype)` (N*K*4
+// bytes written and read again), a float GEMM, the bias add and Qop.dequantize (Qop.py:164-181).  Here
+// the weight stays int8 all the way into LDS (one byte per element from HBM) and becomes bf16, exactly,
+// in registers; the activation is carried as bf16 PLANES so that nothing is lost against the
+// reference's fp32 product:
+//   * bf16 activations: one plane, the tensor itself;
+//   * fp32 activations: hi = bf16(x), lo = bf16(x - hi): x - hi - lo is below 2^-17 |x|, every
+//     bf16 x int8 product is exact in fp32 and the MFMA accumulates in fp32;
+//   * fp16 activations: the same two planes hold an fp16 value exactly (11 significant bits).
+// A small pre-pass (split_planes_kernel) writes the planes into the caller's workspace.
+//
+// Tiling follows the int8 GEMM (miq_gemm_i8.hip): both operands K-contiguous, 128-byte LDS rows with
+// the same chunk swizzle, LDS-DMA staging with out-of-range zero fill for every ragged edge, the
+// weight as the MFMA's first operand.  A K-tile is 128 ELEMENTS: one 128-byte row piece of the weight
+// and, per plane, two 128-byte sub-tiles (k 0-63 and 64-127) of the activation.  A lane reads 16
+// weight bytes (k = 16c .. 16c+15, c = (lane>>4) + 4h) per 16-channel fragment and sub-tile h: two
+// MFMA operands of eight k each, whose activation counterparts are the 16-byte chunks 2*(lane>>4) and
+// 2*(lane>>4)+1 of sub-tile h.  The k order inside an MFMA never has to be known: both operands use
+// the same k -> (lane, slot) map.
+#include "miq_common.h"
+#include "miq_gemm_core.h"
+
+namespace {
+
+using namespace miq;
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+enum : int { kOutRaw = 7 };   // split-K slices: raw fp32 partial sums into a slab
+
+struct W8fArgs {
+    const void* X;      // NP bf16 planes [M,K], plane_stride bytes apart
+    const int8_t* W;    // [N,K]
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int M, N, K;
+    uint32_t plane_stride;
+    int tiles_m, tiles_n;
+    int kt_per_split;   // K-tiles per blockIdx.y slice; 0 = all of K
+};
+
+__device__ __forceinline__ float bf16_round(float x) { return static_cast<float>(static_cast<__bf16>(x)); }
+
+// Eight consecutive activations as fp32 (the rows are 16-byte aligned on this path).
+__device__ __forceinline__ void load8(const float* __restrict__ x, float (&f)[8]) {
+    const v4f a = reinterpret_cast<const v4f*>(x)[0], b = reinterpret_cast<const v4f*>(x)[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[i] = a[i];
+        f[4 + i] = b[i];
+    }
+}
+__device__ __forceinline__ void load8(const _Float16* __restrict__ x, float (&f)[8]) {
+    typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+    const v8h a = *reinterpret_cast<const v8h*>(x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = static_cast<float>(a[i]);
+}
+
+// hi + lo planes of eight consecutive activations.
+template <typename T>
+__device__ __forceinline__ void split8(const T* __restrict__ x, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    float f[8];
+    load8(x, f);
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float fh[2], fl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = f[2 * i + e];
+            fh[e] = bf16_round(v);
+            if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
+                fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+            // (an infinite or NaN value is carried by hi alone)
+            fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
+        }
+        h[i] = pack2_bf16(fh[0], fh[1]);
+        l[i] = pack2_bf16(fl[0], fl[1]);
+    }
+    *reinterpret_cast<uint4*>(hi) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4*>(lo) = uint4{l[0], l[1], l[2], l[3]};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void split_planes_kernel(const T* __restrict__ x, uint16_t* __restrict__ hi,
+                                                           uint16_t* __restrict__ lo, int64_t groups) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < groups; i += 256ll * gridDim.x)
+        split8(x + i * 8, hi + i * 8, lo + i * 8);
+}
+
+// Eight int8 (two dwords) -> eight bf16, exact.
+__device__ __forceinline__ v8bf int8x8_to_bf16(int a, int b) {
+    uint32_t p[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = i ? b : a;
+        p[2 * i] = pack2_bf16(static_cast<float>(static_cast<int8_t>(v)), static_cast<float>(static_cast<int8_t>(v >> 8)));
+        p[2 * i + 1] = pack2_bf16(static_cast<float>(static_cast<int8_t>(v >> 16)), static_cast<float>(v >> 24));
+    }
+    return __builtin_bit_cast(v8bf, uint4{p[0], p[1], p[2], p[3]});
+}
+
+__device__ __forceinline__ float dequant1f(float acc, float bias, float alpha, float beta) {
+    return __fadd_rn(__fmul_rn(__fadd_rn(acc, bias), alpha), beta);
+}
+
+// STAGES = 2: double buffer, one __syncthreads per K-tile.  STAGES > 2: ring of K-tile buffers with
+// STAGES-1 tiles in flight behind a counted vmcnt and one raw barrier per K-tile (the thin problems,
+// whose K-tile of MFMAs is far shorter than a fetch).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArgs g) {
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int XSUB = BM * kTileK;          // one sub-tile of one plane
+    constexpr int XBYTES = NP * 2 * XSUB;
+    constexpr int STAGE = XBYTES + BN * kTileK;
+    constexpr int XPIECES = NP * 2 * BM / 8, WPIECES = BN / 8;   // 8-row x 128-byte DMA pieces
+    static_assert(XPIECES % NWAVES == 0 && WPIECES % NWAVES == 0, "pieces must divide among the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const uint32_t kb = 2u * static_cast<uint32_t>(g.K);   // bytes per activation row
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, (NP - 1) * g.plane_stride + static_cast<uint32_t>(g.M) * kb);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+
+    v4f acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int nt_all = (g.K + kTileK - 1) / kTileK;
+    const int kt0 = g.kt_per_split ? static_cast<int>(blockIdx.y) * g.kt_per_split : 0;
+    const int nt = g.kt_per_split ? (nt_all - kt0 < g.kt_per_split ? nt_all - kt0 : g.kt_per_split) : nt_all;
+    if (g.kt_per_split) g.out = static_cast<float*>(g.out) + static_cast<size_t>(blockIdx.y) * g.M * g.N;
+
+    const int r_in = lane >> 3, slot = lane & 7;
+    auto stage = [&](char* buf, int kt) {
+#pragma unroll
+        for (int i = 0; i < XPIECES / NWAVES; ++i) {
+            const int q = wave + i * NWAVES;              // wave-uniform
+            const int sub = q / (BM / 8), pc = q % (BM / 8);
+            const int p = sub >> 1, h = sub & 1;
+            const int r = pc * 8 + r_in;
+            const int c = slot ^ ((r >> 1) & 7);
+            const uint32_t kbyte = static_cast<uint32_t>(2 * kt + h) * kTileK + c * kChunk;
+            const int row = m0 + r;
+            const uint32_t off = (row < g.M && kbyte < kb) ? p * g.plane_stride + static_cast<uint32_t>(row) * kb + kbyte : kOob;
+            dma16(rx, buf + q * (8 * kTileK), off);
+        }
+#pragma unroll
+        for (int i = 0; i < WPIECES / NWAVES; ++i) {
+            const int piece = wave + i * NWAVES;
+            const int r = piece * 8 + r_in;
+            const int c = slot ^ ((r >> 1) & 7);
+            const int k = kt * kTileK + c * kChunk;
+            const int row = n0 + r;
+            const uint32_t off = (row < g.N && k < g.K) ? static_cast<uint32_t>(row) * g.K + k : kOob;
+            dma16(rw, buf + XBYTES + piece * (8 * kTileK), off);
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wlo[2] = {frag_lane_offset(lane, 0), frag_lane_offset(lane, 1)};
+    const int xlo[2] = {fr * kTileK + (((2 * fq) ^ (fr >> 1)) * kChunk), fr * kTileK + (((2 * fq + 1) ^ (fr >> 1)) * kChunk)};
+
+    auto mma_tile = [&](const char* cur) {
+        const char* wt = cur + XBYTES + wn * WN * kTileK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v8bf wf[2][FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const v4i raw = lds_read16(wt + j * 16 * kTileK + wlo[h]);
+                wf[0][j] = int8x8_to_bf16(raw[0], raw[1]);
+                wf[1][j] = int8x8_to_bf16(raw[2], raw[3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const char* xt = cur + (p * 2 + h) * XSUB + wm * WM * kTileK;
+                    v8bf xf[FM];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) xf[i] = __builtin_bit_cast(v8bf, lds_read16(xt + i * 16 * kTileK + xlo[e]));
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], xf[i], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if constexpr (STAGES == 2) {
+        stage(smem, kt0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) stage(smem + ((t + 1) & 1) * STAGE, kt0 + t + 1);
+            mma_tile(smem + (t & 1) * STAGE);
+            __syncthreads();
+        }
+    } else {
+        constexpr int kLoads = (XPIECES + WPIECES) / NWAVES;
+        constexpr int kKeep = kLoads * (STAGES - 2);
+        static_assert(kKeep <= 63, "vmcnt is a 6-bit counter");
+        const int kt_end = kt0 + nt;   // tiles past the slice are requested past K: zero-filled, no traffic
+        auto stage_or_skip = [&](char* buf, int kt) { stage(buf, kt < kt_end ? kt : nt_all); };
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) stage_or_skip(smem + s * STAGE, kt0 + s);
+        int cur = 0, fill = STAGES - 1;
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKeep) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage_or_skip(smem + fill * STAGE, kt0 + t + STAGES - 1);
+            mma_tile(smem + cur * STAGE);
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // D of a fragment: 4*(lane>>4) + reg -> output channel, lane&15 -> activation row.
+    const int mrow = m0 + wm * WM + (lane & 15);
+    const int ncol = n0 + wn * WN + (lane >> 4) * 4;
+    const bool vec_ok = (g.N & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = ncol + j * 16;
+        float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (OUT != kOutRaw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) {
+                    al[e] = g.alpha[n + e];
+                    if (g.bias) bi[e] = g.bias[n + e];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mrow + i * 16;
+            if (m >= g.M || n >= g.N) continue;
+            const v4f a = acc[i][j];
+            const size_t idx = static_cast<size_t>(m) * g.N + n;
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = OUT == kOutRaw ? a[e] : dequant1f(a[e], bi[e], al[e], g.beta);
+            if constexpr (OUT == kOutBF16) {
+                uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
+                if (vec_ok && n + 3 < g.N) {
+                    *reinterpret_cast<uint2*>(o) = pack4_bf16(y[0], y[1], y[2], y[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
+                }
+            } else {
+                float* o = static_cast<float*>(g.out) + idx;
+                if (vec_ok && n + 3 < g.N) {
+                    *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) o[e] = y[e];
+                }
+            }
+        }
+    }
+}
+
+// Sums the split-K slabs and applies the epilogue.
+template <int OUT>
+__global__ __launch_bounds__(256) void w8f_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, W8fArgs g) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int n = static_cast<int>(idx % g.N);
+        float sum = 0.f;
+        for (int s = 0; s < splits; ++s) sum = __fadd_rn(sum, slabs[s * total + idx]);
+        const float y = dequant1f(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
+        if constexpr (OUT == kOutF32) {
+            static_cast<float*>(g.out)[idx] = y;
+        } else {
+            static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+        }
+    }
+}
+
+// Any K, any alignment: one thread per output, fp32 multiply-adds in k order.
+template <typename T, int OUT>
+__global__ __launch_bounds__(256) void gemm_w8f_any_kernel(const T* __restrict__ x, W8fArgs g) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+        const int64_t m = idx / g.N;
+        const int n = static_cast<int>(idx % g.N);
+        const T* xr = x + m * g.K;
+        const int8_t* wr = g.W + static_cast<int64_t>(n) * g.K;
+        float sum = 0.f;
+        for (int k = 0; k < g.K; ++k) sum = __fadd_rn(sum, __fmul_rn(static_cast<float>(xr[k]), static_cast<float>(wr[k])));
+        const float y = dequant1f(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
+        if constexpr (OUT == kOutF32) {
+            static_cast<float*>(g.out)[idx] = y;
+        } else {
+            static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+        }
+    }
+}
+
+// Tile rows by M; thin problems (few output tiles, deep K) are cut along K into fp32 slabs.
+struct W8fPlan {
+    int bm, bn;
+    int splits, kt_per_split;
+};
+
+W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K) {
+    W8fPlan p{128, 128, 1, 0};
+    if (M <= 16) {
+        p.bm = 16; p.bn = 64;
+    } else if (M <= 32) {
+        p.bm = 32; p.bn = 64;
+    } else if (M <= 64) {
+        p.bm = 64; p.bn = 64;
+    }
+    if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switch
+        const int bm = atoi(t);
+        if (bm == 16 || bm == 32 || bm == 64 || bm == 128) { p.bm = bm; p.bn = bm == 128 ? 128 : 64; }
+    }
+    const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
+    const int64_t nt = ceil_div(K, kTileK);
+    int64_t splits = 1;
+    if (tiles < 160 && nt >= 16) {
+        splits = ceil_div(p.bm == 128 ? 256 : 512, tiles);
+        if (splits > nt / 4) splits = nt / 4;                // at least 4 K-tiles (512 of K) per slice
+        if (splits > K / (8 * M)) splits = K / (8 * M);      // slab traffic (2 * 4*splits*M*N) <= weight bytes N*K
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    if (splits > 1) {
+        p.kt_per_split = static_cast<int>(ceil_div(nt, splits));
+        p.splits = static_cast<int>(ceil_div(nt, p.kt_per_split));
+    }
+    return p;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES>
+int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st) {
+    g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
+    g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
+    constexpr int kLds = STAGES * (NP * 2 * BM + BN) * kTileK;
+    static_assert(kLds <= 160 * 1024, "LDS per workgroup");
+    const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
+    if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_gemm_w8: too many tiles");
+    if (plan.splits > 1) {
+        W8fArgs part = g;
+        part.out = slabs;
+        part.kt_per_split = plan.kt_per_split;
+        auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, kOutRaw, STAGES>;
+        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+        kern<<<dim3(static_cast<unsigned>(nwg), static_cast<unsigned>(plan.splits)), 64 * WAVES_M * WAVES_N, kLds, st>>>(part);
+        if (int rc = check_launch("gemm_w8f_kernel (split-K)")) return rc;
+        const int64_t total = static_cast<int64_t>(g.M) * g.N;
+        const int rgrid = static_cast<int>(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+        w8f_splitk_reduce_kernel<OUT><<<rgrid, 256, 0, st>>>(slabs, plan.splits, g);
+        return check_launch("w8f_splitk_reduce_kernel");
+    }
+    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
+    return check_launch("gemm_w8f_kernel");
+}
+
+template <int NP, int OUT>
+int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t st) {
+    switch (plan.bm) {
+        case 16:
+            return launch_w8f_tile<16, 64, 1, 4, NP, OUT, 4>(g, plan, slabs, st);
+        case 32:
+            return launch_w8f_tile<32, 64, 1, 4, NP, OUT, 4>(g, plan, slabs, st);
+        case 64:
+            return launch_w8f_tile<64, 64, 2, 2, NP, OUT, (NP == 2 ? 3 : 4)>(g, plan, slabs, st);
+        default:
+            return launch_w8f_tile<128, 128, 2, 4, NP, OUT, (NP == 2 ? 2 : 3)>(g, plan, slabs, st);
+    }
+}
+
+template <typename T, int OUT>
+int launch_any(const void* x, const W8fArgs& g, hipStream_t st) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    const int grid = static_cast<int>(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+    gemm_w8f_any_kernel<T, OUT><<<grid, 256, 0, st>>>(static_cast<const T*>(x), g);
+    return check_launch("gemm_w8f_any_kernel");
+}
+
+size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
+    return x_dtype == MIQ_BF16 ? 0 : static_cast<size_t>(round_up(M * K * 2, 256));
+}
+size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K) {
+    if (K % 16 != 0) return 0;
+    const W8fPlan p = plan_w8f(M, N, K);
+    return p.splits > 1 ? static_cast<size_t>(round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
+}
+
+}  // namespace
+
+extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return 0;
+    return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K);
+}
+
+extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
+                           const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "miq_gemm_w8: negative size (M=%lld N=%lld K=%lld)",
+                (long long)M, (long long)N, (long long)K);
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_gemm_w8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_gemm_w8: out_dtype must be MIQ_F32 or MIQ_BF16 (got %d)", out_dtype);
+    if (M == 0 || N == 0) return MIQ_OK;
+    MIQ_REQUIRE(out && alpha, MIQ_EINVAL, "miq_gemm_w8: null output or alpha");
+    MIQ_REQUIRE(K == 0 || (x && W), MIQ_EINVAL, "miq_gemm_w8: null operand");
+    MIQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && M * K < (1ll << 29) && N * K < (1ll << 31),
+                MIQ_ERANGE, "miq_gemm_w8: operands are indexed with 31-bit byte offsets (M*K < 2^29, N*K < 2^31)");
+    const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2, esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(miq::aligned(x, xsz) && miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
+                "miq_gemm_w8: x/out/alpha/bias not aligned to their element size");
+    hipStream_t st = miq::as_stream(stream);
+
+    W8fArgs g{x, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0u, 0, 0, 0};
+    const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
+    const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(x, 16) && miq::aligned(W, 16) && out_vec_ok;
+    if (!mfma_ok) {
+        if (out_dtype == MIQ_F32) {
+            if (x_dtype == MIQ_F32) return launch_any<float, kOutF32>(x, g, st);
+            if (x_dtype == MIQ_F16) return launch_any<_Float16, kOutF32>(x, g, st);
+            return launch_any<__bf16, kOutF32>(x, g, st);
+        }
+        if (x_dtype == MIQ_F32) return launch_any<float, kOutBF16>(x, g, st);
+        if (x_dtype == MIQ_F16) return launch_any<_Float16, kOutBF16>(x, g, st);
+        return launch_any<__bf16, kOutBF16>(x, g, st);
+    }
+
+    const size_t need = miq_gemm_w8_workspace(x_dtype, M, N, K);
+    if (need) {
+        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                    "miq_gemm_w8: this call needs %zu bytes of workspace (got %zu): see miq_gemm_w8_workspace", need,
+                    workspace_bytes);
+        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_w8: workspace must be 256-byte aligned");
+    }
+    const size_t pb = plane_bytes(x_dtype, M, K);
+    float* slabs = w8f_slab_bytes(M, N, K) ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * pb) : nullptr;
+    const W8fPlan plan = plan_w8f(M, N, K);
+    if (x_dtype != MIQ_BF16) {
+        uint16_t* hi = static_cast<uint16_t*>(workspace);
+        uint16_t* lo = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + pb);
+        const int64_t groups = M * K / 8;
+        const int grid = static_cast<int>(groups / 256 + 1 < 8192 ? groups / 256 + 1 : 8192);
+        if (x_dtype == MIQ_F32)
+            split_planes_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float*>(x), hi, lo, groups);
+        else
+            split_planes_kernel<_Float16><<<grid, 256, 0, st>>>(static_cast<const _Float16*>(x), hi, lo, groups);
+        if (int rc = check_launch("split_planes_kernel")) return rc;
+        g.X = hi;
+        g.plane_stride = static_cast<uint32_t>(pb);
+        return out_dtype == MIQ_F32 ? launch_w8f<2, kOutF32>(g, plan, slabs, st) : launch_w8f<2, kOutBF16>(g, plan, slabs, st);
+    }
+    return out_dtype == MIQ_F32 ? launch_w8f<1, kOutF32>(g, plan, slabs, st) : launch_w8f<1, kOutBF16>(g, plan, slabs, st);
+}

@@ -103,17 +103,22 @@ class _QuantizerBase(nn.Module):
 
     def _float_product(self, x, bias, alpha, beta):
         w = _to_gpu(self.weight)
+        if not self.cnn:
+            # Linear: the int8 weight goes to the matrix cores as it is stored (no float copy of it), with the
+            # bias / scale epilogue fused (miq_gemm_w8).
+            lead = x.shape[:-1]
+            if x.dtype == torch.float64:
+                x = x.to(torch.float32)
+            out = _native.gemm_w8(x.reshape(-1, x.shape[-1]).contiguous(), w, bias=bias, alpha=alpha, beta=beta)
+            return out.view(*lead, out.shape[-1])
+        # Conv2d on float activations: a library float convolution on a cached float copy of the weight,
+        # then the fused bias / scale epilogue.
         if self._wfloat is None or self._wfloat.dtype != x.dtype or self._wfloat.device != w.device \
                 or self._wfloat_src is not self.weight:
             self._wfloat, self._wfloat_src = w.to(x.dtype), self.weight
-        if self.cnn:
-            y = F.conv2d(x, self._wfloat, stride=self.stride, padding=self.padding, dilation=self.dilation,
-                         groups=self.groups)
-            return _native.epilogue_channels_f32(y.contiguous(), bias, alpha, beta)
-        y = F.linear(x, self._wfloat)
-        lead = y.shape[:-1]
-        out = _native.epilogue_channels_f32(y.reshape(-1, y.shape[-1]).contiguous(), bias, alpha, beta)
-        return out.view(*lead, out.shape[-1])
+        y = F.conv2d(x, self._wfloat, stride=self.stride, padding=self.padding, dilation=self.dilation,
+                     groups=self.groups)
+        return _native.epilogue_channels_f32(y.contiguous(), bias, alpha, beta)
 
     def _run(self, x, bias, alpha, beta):
         home = x.device

@@ -1,0 +1,149 @@
+"""Weight-only Linear on floating-point activations (miq_gemm_w8, through the C ABI) against an fp64 product.
+
+Bar: the reference computes this product in fp32 (`F.linear(x, weight.to(x.dtype))`,
+quant/Weight_Only/Quantizer.py:79-91) and the dequantised output must agree within 1e-3 relative.  The kernel
+carries fp32 activations as two bf16 planes (residual below 2^-17 |x|) with exact bf16 x int8 products and fp32
+accumulation, so the test holds it to a far tighter bound than 1e-3: per element
+    |y - ref| <= 5e-5 * alpha[n] * (sum_k |x[m,k] * w[n,k]| + |bias[n]|)
+(the term a cancelling sum is measured against), and 1e-4 of the output's norm overall.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def N():
+    from quantization_amd import _native
+    _native.lib()
+    return _native
+
+
+def make(M, Nn, K, xdt, seed, bias=True, wide=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g)
+    if wide:
+        x = x * torch.exp(4 * torch.randn(M, K, generator=g))   # magnitudes over many binades
+        if xdt == "f16":
+            x = x.clamp(-60000.0, 60000.0)
+    x = x.to(DT[xdt])
+    w = torch.randint(-128, 128, (Nn, K), generator=g, dtype=torch.int32).to(torch.int8)
+    alpha = torch.rand(Nn, generator=g) * 0.02 + 1e-4
+    b = torch.randn(Nn, generator=g) * 10 if bias else None
+    return x, w, b, alpha
+
+
+def check(N, x, w, b, alpha, beta=0.0, out_dtype=torch.float32):
+    y = N.gemm_w8(x.cuda(), w.cuda(), bias=None if b is None else b.cuda(), alpha=alpha.cuda(), beta=beta,
+                  out_dtype=out_dtype)
+    torch.cuda.synchronize()
+    assert y.dtype == out_dtype and tuple(y.shape) == (x.shape[0], w.shape[0])
+    xd, wd = x.double(), w.double()
+    bd = torch.zeros(w.shape[0], dtype=torch.float64) if b is None else b.double()
+    ref = (xd @ wd.t() + bd) * alpha.double() + beta
+    mag = (xd.abs() @ wd.abs().t() + bd.abs()) * alpha.double() + abs(beta)
+    err = (y.cpu().double() - ref).abs()
+    tol = 5e-5 * mag + 1e-30
+    if out_dtype == torch.bfloat16:
+        tol = tol + ref.abs() * 2.0 ** -8
+    worst = float((err / tol).max()) if err.numel() else 0.0
+    assert worst <= 1.0, f"worst error / tolerance = {worst:.3f}"
+    if err.numel() and out_dtype == torch.float32:
+        assert float(err.norm() / ref.norm().clamp_min(1e-30)) <= 1e-4
+    return y
+
+
+SHAPES = [
+    (1, 64, 128), (3, 10, 16), (16, 64, 256), (17, 100, 48), (33, 257, 400), (64, 64, 4096 + 16),
+    (65, 130, 1040), (129, 96, 2064), (257, 300, 528), (300, 1000, 640), (5, 7, 16), (1, 1, 16),
+]
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("M,Nn,K", SHAPES)
+def test_w8f_shapes(N, M, Nn, K, xdt):
+    x, w, b, alpha = make(M, Nn, K, xdt, seed=M * 7 + Nn * 3 + K)
+    check(N, x, w, b, alpha)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("M,Nn,K", [(4, 33, 24), (9, 12, 7), (2, 5, 1), (40, 17, 100)])
+def test_w8f_unaligned_k_takes_the_scalar_kernel(N, M, Nn, K, xdt):
+    x, w, b, alpha = make(M, Nn, K, xdt, seed=K)
+    check(N, x, w, b, alpha, beta=0.25)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,Nn,K", [(1, 512, 8192), (8, 1024, 4096), (32, 256, 14336), (64, 1000, 6144), (200, 512, 4096)])
+def test_w8f_split_k(N, M, Nn, K, xdt):
+    from quantization_amd import _native
+    assert _native.lib().miq_gemm_w8_workspace(0, M, Nn, K) > 2 * ((M * K * 2 + 255) // 256 * 256), "expected a split-K plan"
+    x, w, b, alpha = make(M, Nn, K, xdt, seed=K + M)
+    check(N, x, w, b, alpha)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16"])
+def test_w8f_wide_range_activations(N, xdt):
+    x, w, b, alpha = make(96, 200, 1024, xdt, seed=5, wide=True)
+    check(N, x, w, None, alpha)
+
+
+def test_w8f_f16_planes_are_exact(N):
+    """An fp16 value is the sum of its two bf16 planes: integer-valued fp16 activations give the exact integer sums."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-2048, 2049, (40, 512), generator=g).to(torch.float16)
+    w = torch.randint(-128, 128, (72, 512), generator=g, dtype=torch.int32).to(torch.int8)
+    one = torch.ones(72)
+    y = N.gemm_w8(x.cuda(), w.cuda(), alpha=one.cuda()).cpu()
+    ref = x.double() @ w.double().t()     # |sum| < 2^24: exact in fp32 whatever the order
+    assert float(ref.abs().max()) < 2 ** 24
+    assert torch.equal(y.double(), ref)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "bf16"])
+def test_w8f_bf16_out_and_no_bias(N, xdt):
+    x, w, b, alpha = make(70, 136, 768, xdt, seed=11, bias=False)
+    check(N, x, w, None, alpha, beta=-0.5, out_dtype=torch.bfloat16)
+
+
+def test_w8f_specials_propagate(N):
+    x, w, b, alpha = make(8, 64, 256, "f32", seed=2)
+    x[1, 5] = float("inf")
+    x[2, 7] = float("nan")
+    x[3, 9] = 3.4e38          # rounds past the largest bf16: must stay finite
+    w[:, 9] = 0
+    y = N.gemm_w8(x.cuda(), w.cuda(), bias=b.cuda(), alpha=alpha.cuda()).cpu()
+    assert torch.isnan(y[2]).all() and not torch.isfinite(y[1]).any()
+    assert torch.isfinite(y[0]).all() and torch.isfinite(y[3]).all()
+
+
+def test_w8f_llama_mlp_shape(N):
+    x, w, b, alpha = make(256, 14336, 4096, "f32", seed=0)
+    check(N, x, w, b, alpha)
+    x, w, b, alpha = make(16, 4096, 14336, "bf16", seed=1)
+    check(N, x, w, b, alpha)
+
+
+def test_w8f_argument_checks(N):
+    x = torch.randn(4, 32).cuda()
+    w = torch.zeros(8, 32, dtype=torch.int8).cuda()
+    a = torch.ones(8).cuda()
+    with pytest.raises(RuntimeError):
+        N.gemm_w8(x.cpu(), w, alpha=a)
+    with pytest.raises(RuntimeError):
+        N.gemm_w8(x, w[:, :16].contiguous(), alpha=a)
+    with pytest.raises(RuntimeError):
+        N.gemm_w8(x.to(torch.int8), w, alpha=a)
+    with pytest.raises(RuntimeError):
+        N.gemm_w8(x, w, alpha=None)
+    with pytest.raises(RuntimeError):
+        N.gemm_w8(x, w, alpha=a, out_dtype=torch.int32)
+    L = N.lib()
+    assert L.miq_gemm_w8(x.data_ptr(), 0, w.data_ptr(), 4, 8, 32, None, a.data_ptr(), 0.0, None, 0, None, 0, None) == -1
+    assert L.miq_gemm_w8(x.data_ptr(), 5, w.data_ptr(), 4, 8, 32, None, a.data_ptr(), 0.0, x.data_ptr(), 0, None, 0, None) == -1
+    out = torch.empty(4, 8).cuda()
+    assert L.miq_gemm_w8(x.data_ptr(), 0, w.data_ptr(), 4, 8, 32, None, a.data_ptr(), 0.0, out.data_ptr(), 0, None, 0, None) == -3
+    assert N.gemm_w8(torch.empty(0, 32).cuda(), w, alpha=a).shape == (0, 8)
