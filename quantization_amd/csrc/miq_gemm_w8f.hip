@@ -21,6 +21,8 @@
 // MFMA operands of eight k each, whose activation counterparts are the 16-byte chunks 2*(lane>>4) and
 // 2*(lane>>4)+1 of sub-tile h.  The k order inside an MFMA never has to be known: both operands use
 // the same k -> (lane, slot) map.
+#include <algorithm>
+
 #include "miq_common.h"
 #include "miq_gemm_core.h"
 
@@ -321,30 +323,46 @@ __global__ __launch_bounds__(256) void gemm_w8f_any_kernel(const T* __restrict__
     }
 }
 
-// Tile rows by M; thin problems (few output tiles, deep K) are cut along K into fp32 slabs.
+// Tile shape by M, from a measured sweep on the Llama-3-8B MLP weights ([14336,4096] and [4096,14336];
+// tools/w8f_sweep.py).  The bytes a launch moves from L2 into LDS are
+//     N*K * ceil(M / bm)  (weight)  +  planes * 2*M*K * ceil(N / bn)  (activation planes),
+// but up to M = 128 the kernels are bound by how many workgroups stream at once rather than by those
+// bytes: 32-row tiles (two or more workgroups per CU) beat 64- and 128-row ones, and 256-channel tiles pay
+// once the activation planes outweigh the weight tile.  Thin problems (few output tiles, deep K) are cut
+// along K into fp32 slabs so that every CU streams.
 struct W8fPlan {
     int bm, bn;
     int splits, kt_per_split;
 };
 
-W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K) {
+W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
     W8fPlan p{128, 128, 1, 0};
     if (M <= 16) {
         p.bm = 16; p.bn = 64;
     } else if (M <= 32) {
-        p.bm = 32; p.bn = 64;
+        p.bm = 32; p.bn = planes == 2 ? 256 : 64;
     } else if (M <= 64) {
-        p.bm = 64; p.bn = 64;
+        p.bm = planes == 2 ? 64 : 32; p.bn = planes == 2 ? 256 : 64;
+    } else if (M <= 128) {
+        p.bm = 32; p.bn = 256;
+    } else if (planes == 1 && ceil_div(M, 128) * ceil_div(N, 256) >= 200) {
+        p.bn = 256;   // one activation plane leaves LDS for a 256-channel tile: 900-1080 against 770-860 TFLOP/s
     }
-    if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switch
+    while (p.bm < 128 && p.bn > 64 && N < 2 * p.bn) p.bn >>= 1;   // narrow weights: no empty tile columns
+    if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switches
         const int bm = atoi(t);
-        if (bm == 16 || bm == 32 || bm == 64 || bm == 128) { p.bm = bm; p.bn = bm == 128 ? 128 : 64; }
+        if (bm == 16 || bm == 32 || bm == 64 || bm == 128 || (bm == 256 && planes == 1)) { p.bm = bm; p.bn = bm >= 128 ? 128 : 64; }
+    }
+    if (const char* t = dev_switch("MIQ_W8F_BN")) {
+        const int bn = atoi(t);
+        if (p.bm < 128 && (bn == 64 || bn == 128 || bn == 256)) p.bn = bn;
+        if (p.bm == 128 && planes == 1 && (bn == 128 || bn == 256)) p.bn = bn;
     }
     const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
     const int64_t nt = ceil_div(K, kTileK);
     int64_t splits = 1;
     if (tiles < 160 && nt >= 16) {
-        splits = ceil_div(p.bm == 128 ? 256 : 512, tiles);
+        splits = ceil_div(p.bm == 128 || p.bn > 64 ? 256 : 512, tiles);
         if (splits > nt / 4) splits = nt / 4;                // at least 4 K-tiles (512 of K) per slice
         if (splits > K / (8 * M)) splits = K / (8 * M);      // slab traffic (2 * 4*splits*M*N) <= weight bytes N*K
         if (splits > 32) splits = 32;
@@ -357,12 +375,20 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES>
+// Deepest ring (at most four K-tiles) that fits the 160 KiB of LDS.
+constexpr int w8f_stages(int bm, int bn, int np) {
+    const int stage = (np * 2 * bm + bn) * kTileK;
+    const int fit = (160 * 1024) / stage;
+    return fit > 4 ? 4 : fit;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT>
 int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st) {
+    constexpr int STAGES = w8f_stages(BM, BN, NP);
+    static_assert(STAGES >= 2, "a tile needs two K-tile buffers");
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
     constexpr int kLds = STAGES * (NP * 2 * BM + BN) * kTileK;
-    static_assert(kLds <= 160 * 1024, "LDS per workgroup");
     const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_gemm_w8: too many tiles");
     if (plan.splits > 1) {
@@ -386,16 +412,23 @@ int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st
 
 template <int NP, int OUT>
 int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t st) {
-    switch (plan.bm) {
-        case 16:
-            return launch_w8f_tile<16, 64, 1, 4, NP, OUT, 4>(g, plan, slabs, st);
-        case 32:
-            return launch_w8f_tile<32, 64, 1, 4, NP, OUT, 4>(g, plan, slabs, st);
-        case 64:
-            return launch_w8f_tile<64, 64, 2, 2, NP, OUT, (NP == 2 ? 3 : 4)>(g, plan, slabs, st);
-        default:
-            return launch_w8f_tile<128, 128, 2, 4, NP, OUT, (NP == 2 ? 2 : 3)>(g, plan, slabs, st);
+    switch (plan.bm * 1000 + plan.bn) {
+        case 16064: return launch_w8f_tile<16, 64, 1, 4, NP, OUT>(g, plan, slabs, st);
+        case 16128: return launch_w8f_tile<16, 128, 1, 4, NP, OUT>(g, plan, slabs, st);
+        case 16256: return launch_w8f_tile<16, 256, 1, 4, NP, OUT>(g, plan, slabs, st);
+        case 32064: return launch_w8f_tile<32, 64, 1, 4, NP, OUT>(g, plan, slabs, st);
+        case 32128: return launch_w8f_tile<32, 128, 1, 4, NP, OUT>(g, plan, slabs, st);
+        case 32256: return launch_w8f_tile<32, 256, 1, 8, NP, OUT>(g, plan, slabs, st);
+        case 64064: return launch_w8f_tile<64, 64, 2, 2, NP, OUT>(g, plan, slabs, st);
+        case 64128: return launch_w8f_tile<64, 128, 2, 2, NP, OUT>(g, plan, slabs, st);
+        case 64256: return launch_w8f_tile<64, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
+        default: break;
     }
+    if constexpr (NP == 1) {   // one activation plane leaves LDS for wider tiles
+        if (plan.bm == 128 && plan.bn == 256) return launch_w8f_tile<128, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
+        if (plan.bm == 256) return launch_w8f_tile<256, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
+    }
+    return launch_w8f_tile<128, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
 }
 
 template <typename T, int OUT>
@@ -409,9 +442,9 @@ int launch_any(const void* x, const W8fArgs& g, hipStream_t st) {
 size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
     return x_dtype == MIQ_BF16 ? 0 : static_cast<size_t>(round_up(M * K * 2, 256));
 }
-size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K) {
+size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K, int planes) {
     if (K % 16 != 0) return 0;
-    const W8fPlan p = plan_w8f(M, N, K);
+    const W8fPlan p = plan_w8f(M, N, K, planes);
     return p.splits > 1 ? static_cast<size_t>(round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
 }
 
@@ -419,7 +452,7 @@ size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K) {
 
 extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return 0;
-    return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K);
+    return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K, x_dtype == MIQ_BF16 ? 1 : 2);
 }
 
 extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
@@ -463,8 +496,9 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
         MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_w8: workspace must be 256-byte aligned");
     }
     const size_t pb = plane_bytes(x_dtype, M, K);
-    float* slabs = w8f_slab_bytes(M, N, K) ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * pb) : nullptr;
-    const W8fPlan plan = plan_w8f(M, N, K);
+    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    float* slabs = w8f_slab_bytes(M, N, K, planes) ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * pb) : nullptr;
+    const W8fPlan plan = plan_w8f(M, N, K, planes);
     if (x_dtype != MIQ_BF16) {
         uint16_t* hi = static_cast<uint16_t*>(workspace);
         uint16_t* lo = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + pb);

@@ -127,6 +127,13 @@ def test_w8f_llama_mlp_shape(N):
     check(N, x, w, b, alpha)
 
 
+@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+def test_w8f_large_m_tiles(N, xdt):
+    """M > 128 with enough 128 x 256 tiles to fill the chip (bf16 takes that tile), ragged in all three dimensions."""
+    x, w, b, alpha = make(1300, 5000, 272, xdt, seed=21)
+    check(N, x, w, b, alpha)
+
+
 def test_w8f_argument_checks(N):
     x = torch.randn(4, 32).cuda()
     w = torch.zeros(8, 32, dtype=torch.int8).cuda()
