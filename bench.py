@@ -54,6 +54,37 @@ def profiled_traffic(kernel):
         return None
 
 
+def weight_only_float(N_, dev):
+    """The weight-only Linear on floating-point activations (miq_gemm_w8) on the Llama-3-8B gate/up weight
+    [14336,4096]: whole call (the activation-plane pre-pass of fp32 inputs included), HIP events per call.
+    Decode sizes are priced against HBM bandwidth on their algorithmic bytes (int8 weight once + activations +
+    fp32 output); M = 256 against the dense bf16 MFMA peak on 2*M*N*K."""
+    Nn, K = 14336, 4096
+    w = torch.randint(-128, 128, (Nn, K), dtype=torch.int32, device=dev).to(torch.int8)
+    alpha = torch.rand(Nn, device=dev) * 0.01
+    res = {"weight": f"int8 [{Nn},{K}]", "out_dtype": "float32"}
+    for M, dt in ((16, torch.bfloat16), (16, torch.float32), (256, torch.bfloat16), (256, torch.float32)):
+        x = torch.randn(M, K, device=dev).to(dt)
+        out = torch.empty(M, Nn, device=dev)
+
+        def step():
+            N_.gemm_w8(x, w, alpha=alpha, out=out)
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        ts = sorted(event_times(step, 50))
+        ms = ts[len(ts) // 2]
+        nbytes = Nn * K + M * K * x.element_size() + M * Nn * 4
+        entry = {"call_ms": round(ms, 4), "weight_GBps": round(Nn * K / (ms * 1e-3) / 1e9, 1),
+                 "TFLOPs": round(2.0 * M * Nn * K / (ms * 1e-3) / 1e12, 1)}
+        if M <= 16:
+            entry["roofline"] = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "algorithmic_bytes": nbytes}
+        res[f"M{M}_{str(dt).split('.')[-1]}"] = entry
+    return res
+
+
 def cpu_baseline(K, N, sample_rows, seed):
     """Reference CPU path on a bounded sample: quantize a [1024, K] slab of the weight with the
     reference's row loop, then weight-only forward of `sample_rows` rows against the full weight."""
@@ -264,6 +295,8 @@ def main():
                 "gemm_kernel_ms": round(k_ms, 4),
                 "note": "the all-gather of step i overlaps the GEMM of step i+1; a step costs max(gather, GEMM)",
             }
+        if world == 1:
+            line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)

@@ -243,9 +243,44 @@ def pool_cases(mods):
     return out
 
 
+def wo_forward_float_cases(mods):
+    """Weight-only Quantizer.from_float + forward of nn.Linear on REAL-valued activations (the reference's fp32
+    product; bf16 activations for one case, which the reference multiplies in bf16)."""
+    Quantizer = mods["Quantizer"].Quantizer
+    out = {}
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(123)
+    cases = {
+        "f32_lin_300_130": (torch.nn.Linear(300, 130), (37, 300), torch.float32, 1.0),
+        "f32_lin_1024_40_nobias": (torch.nn.Linear(1024, 40, bias=False), (8, 1024), torch.float32, 1.0),
+        "f32_lin_48_200_wide": (torch.nn.Linear(48, 200), (65, 48), torch.float32, 50.0),
+        "f32_lin_2048_32": (torch.nn.Linear(2048, 32), (2, 2048), torch.float32, 0.1),
+        "bf16_lin_256_72": (torch.nn.Linear(256, 72), (19, 256), torch.bfloat16, 1.0),
+    }
+    for name, (mod, xshape, dt, mag) in cases.items():
+        ql = Quantizer.from_float(module=mod, data_metry=Q_PARAMS, quantize_output=False)
+        x = (torch.randn(xshape, generator=g) * mag).to(dt)
+        if dt != torch.float32:
+            ql.bias = None if ql.bias is None else torch.nn.Parameter(ql.bias.to(dt))
+        y = ql(x)
+        out[name + "/w"] = as_f32(mod.weight)
+        if mod.bias is not None:
+            out[name + "/bias"] = as_f32(mod.bias)
+        out[name + "/x"] = as_f32(x)
+        out[name + "/q"] = ql.weight.numpy()
+        out[name + "/scales"] = as_f32(ql.weight_quant.scales).reshape(-1)
+        out[name + "/y"] = as_f32(y)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["wo_float"]:
+        wo = load_ref("Weight_Only")
+        np.savez_compressed(os.path.join(OUT, "wo_forward_float.npz"), **wo_forward_float_cases(wo))
+        print("wo_forward_float.npz", os.path.getsize(os.path.join(OUT, "wo_forward_float.npz")))
+        return
     if sys.argv[1:] == ["pools"]:
         wa = load_ref("Weight_Activation")
         np.savez_compressed(os.path.join(OUT, "pools.npz"), **pool_cases(wa))
@@ -254,6 +289,7 @@ def main():
     wo = load_ref("Weight_Only")
     np.savez_compressed(os.path.join(OUT, "quantizer_wo.npz"), **quantizer_cases(wo["Qop"].Qop))
     np.savez_compressed(os.path.join(OUT, "wo_forward.npz"), **wo_forward_cases(wo))
+    np.savez_compressed(os.path.join(OUT, "wo_forward_float.npz"), **wo_forward_float_cases(wo))
     np.savez_compressed(os.path.join(OUT, "config1_models.npz"), **config1_models(wo))
     wa = load_ref("Weight_Activation")
     np.savez_compressed(os.path.join(OUT, "quantizer_wa.npz"), **quantizer_cases(wa["Qop"].Qop, full=False))

@@ -199,6 +199,19 @@ def wo_linear_forward(x_i8, wq, scale, bias=None):
     return epilogue(acc, bias, np.asarray(scale).reshape(-1), 0.0, channel_axis=1)
 
 
+def wo_linear_forward_float(x, wq, scale, bias=None):
+    """Weight-only Quantizer.forward for a Linear layer on real-valued activations.
+
+    quant/Weight_Only/Quantizer.py:79-91: F.linear(x, weight.to(x.dtype)) in the activation's precision, `+ bias`,
+    then Qop.dequantize (Qop.py:164-181): scale * (y - 0).  The reference's fp32 product sums in an order its BLAS
+    chooses; this restatement sums in float64 and rounds once, which every fp32 summation order agrees with to
+    about 1e-6 relative to sum_k |x*w| -- far inside the 1e-3 the outputs are compared at.
+    x float [M,K], wq int8 [N,K], scale fp32 [N] (or [N,1]), bias fp32 [N] or None.
+    """
+    acc = np.asarray(x, dtype=np.float64) @ np.asarray(wq, dtype=np.float64).T
+    return epilogue(acc.astype(np.float32), bias, np.asarray(scale).reshape(-1), 0.0, channel_axis=1)
+
+
 def wo_conv2d_forward(x_i8, wq, scale, bias=None, stride=1, padding=0):
     """Weight-only Quantizer.forward for a Conv2d layer (quant/Weight_Only/Quantizer.py:72-86)."""
     acc = conv2d_int8(x_i8, wq, stride, padding)

@@ -7,10 +7,17 @@ accumulation, so the test holds it to a far tighter bound than 1e-3: per element
     |y - ref| <= 5e-5 * alpha[n] * (sum_k |x[m,k] * w[n,k]| + |bias[n]|)
 (the term a cancelling sum is measured against), and 1e-4 of the output's norm overall.
 """
+import numpy as np
 import pytest
 import torch
 
+from conftest import Golden
+from oracle import oracle_np as O
+
 pytestmark = pytest.mark.gpu
+
+FF = Golden("wo_forward_float.npz")
+Q_PARAMS = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
 
 DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
@@ -54,6 +61,37 @@ def check(N, x, w, b, alpha, beta=0.0, out_dtype=torch.float32):
     if err.numel() and out_dtype == torch.float32:
         assert float(err.norm() / ref.norm().clamp_min(1e-30)) <= 1e-4
     return y
+
+
+@pytest.mark.parametrize("case", FF.cases())
+def test_w8f_golden_reference_outputs(N, case):
+    """The reference's own Quantizer.forward outputs on real-valued activations (fixture made by
+    oracle/gen_golden.py from the reference's Python), through the C ABI and through the drop-in layer."""
+    x, q, s, ref = FF.get(case, "x"), FF.get(case, "q"), FF.get(case, "scales"), FF.get(case, "y")
+    bias = FF.get(case, "bias")
+    xdt = torch.bfloat16 if case.startswith("bf16") else torch.float32
+    xt = torch.from_numpy(x).to(xdt)
+    y = N.gemm_w8(xt.cuda(), torch.from_numpy(q).cuda(), bias=None if bias is None else torch.from_numpy(bias).cuda(),
+                  alpha=torch.from_numpy(s).cuda()).cpu().numpy()
+    mag = (np.abs(x).astype(np.float64) @ np.abs(q).astype(np.float64).T + (0 if bias is None else np.abs(bias))) * s
+    # against the oracle: 5e-5 of the sum of magnitudes; against the reference: 1e-3 (bf16 activations: the
+    # reference rounds its product to bf16, so bf16 resolution)
+    np.testing.assert_array_less(np.abs(y - O.wo_linear_forward_float(x, q, s, bias)), 5e-5 * mag + 1e-30)
+    np.testing.assert_array_less(np.abs(y - ref), (2.0 ** -6 if xdt == torch.bfloat16 else 1e-3) * np.maximum(np.abs(ref), 1e-2 * mag) + 1e-30)
+
+    from quantization_amd.quant.Weight_Only import Quantizer
+    lin = torch.nn.Linear(q.shape[1], q.shape[0], bias=bias is not None)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(FF.get(case, "w")))
+        if bias is not None:
+            lin.bias.copy_(torch.from_numpy(bias))
+    ql = Quantizer.from_float(module=lin, data_metry=Q_PARAMS, quantize_output=False)
+    np.testing.assert_array_equal(ql.weight.cpu().numpy(), q)
+    y2 = ql(xt.cuda()).float().cpu().numpy()
+    np.testing.assert_array_equal(y2, y)
+    y3 = ql(xt)          # host activations are staged to the GPU and the result comes home
+    assert y3.device.type == "cpu"
+    np.testing.assert_array_equal(y3.float().numpy(), y)
 
 
 SHAPES = [

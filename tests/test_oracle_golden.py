@@ -56,6 +56,26 @@ def test_wo_forward_matches_reference(case):
     np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
 
 
+FF = Golden("wo_forward_float.npz")
+
+
+@pytest.mark.parametrize("case", FF.cases())
+def test_wo_forward_float_matches_reference(case):
+    """Real-valued activations: the oracle's float64-summed product against the reference's own output, at the
+    1e-3 relative bar (measured against sum_k |x*w|, the scale a cancelling sum is resolved at); bf16
+    activations, which the reference multiplies and rounds in bf16, at bf16 resolution."""
+    x, q, s = FF.get(case, "x"), FF.get(case, "q"), FF.get(case, "scales")
+    bias = FF.get(case, "bias")
+    q2, s2, _ = O.quantize_channel_sym_int8(FF.get(case, "w"))
+    np.testing.assert_array_equal(q2, q)
+    np.testing.assert_array_equal(s2.reshape(-1), s)
+    y = O.wo_linear_forward_float(x, q, s, bias)
+    ref = FF.get(case, "y")
+    mag = (np.abs(x).astype(np.float64) @ np.abs(q).astype(np.float64).T + (0 if bias is None else np.abs(bias))) * s
+    rel = 2.0 ** -6 if case.startswith("bf16") else 1e-5
+    assert np.all(np.abs(y - ref) <= rel * mag + 1e-30), float(np.max(np.abs(y - ref) / mag))
+
+
 def test_wa_epilogue_matches_reference():
     for name, conv in (("conv1", True), ("fc2", False)):
         x = WA.get(name, "x")
