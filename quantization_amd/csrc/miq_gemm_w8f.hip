@@ -375,7 +375,8 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
     return p;
 }
 
-// Deepest ring (at most four K-tiles) that fits the 160 KiB of LDS.
+// Deepest ring (at most four K-tiles) that fits the 160 KiB of LDS.  (Six- and eight-deep rings of the 16- and
+// 32-row tiles were measured: equal at best, up to 1.7x slower where they cost a second workgroup per CU.)
 constexpr int w8f_stages(int bm, int bn, int np) {
     const int stage = (np * 2 * bm + bn) * kTileK;
     const int fit = (160 * 1024) / stage;

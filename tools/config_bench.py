@@ -3,7 +3,8 @@
 
   config 3  ResNet-18's twenty convolutions at batch 256 (int8 in, int32 / bf16 out), per layer and in total
   config 4  Llama-3-8B MLP (gate, up [14336,4096]; down [4096,14336]): quantize once, then the three int8
-            matmuls per token batch M = 1 .. 256 (fp32 out, fused dequant epilogue)
+            matmuls per token batch M = 1 .. 256 (fp32 out, fused dequant epilogue), and the same stack on
+            bf16 / fp32 activations (the weight-only forward, miq_gemm_w8)
   config 5  Llama-3-70B shapes on ONE GPU ([28672,8192], [8192,28672], [8192,8192]) at M = 256, 2048, 8192
             (the column-sharded run over 2/4/8 GPUs is bench.py --gpus N)
 
@@ -90,6 +91,19 @@ def config4():
             us += med_us(lambda: N.gemm_i8(x, wq, alpha=sc, out=out))
         ops = 2.0 * M * 3 * 14336 * 4096
         print(f"  M={M:3d}: gate+up+down {us:6.1f} us  {ops / us / 1e6:7.1f} TOPS  weights at {3 * 14336 * 4096 / us / 1e3:5.0f} GB/s", flush=True)
+    # the same stack as the reference's weight-only layers run it: floating-point activations (miq_gemm_w8)
+    for dt in (torch.bfloat16, torch.float32):
+        for M in (1, 16, 64, 256):
+            xa, xd = torch.randn(M, 4096, device="cuda").to(dt), torch.randn(M, 14336, device="cuda").to(dt)
+            us = 0.0
+            for name in ("gate", "up", "down"):
+                wq, sc = q[name]
+                x = xd if name == "down" else xa
+                out = torch.empty(M, wq.shape[0], device="cuda")
+                us += med_us(lambda: N.gemm_w8(x, wq, alpha=sc, out=out))
+            ops = 2.0 * M * 3 * 14336 * 4096
+            print(f"  weight-only, {str(dt).split('.')[-1]} activations, M={M:3d}: gate+up+down {us:6.1f} us  {ops / us / 1e6:7.1f} TFLOP/s  "
+                  f"weights at {3 * 14336 * 4096 / us / 1e3:5.0f} GB/s", flush=True)
 
 
 def config5():
