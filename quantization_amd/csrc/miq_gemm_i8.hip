@@ -787,7 +787,8 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const int64_t big_tiles = ceil_div(M, 256) * ceil_div(N, 256);
     // (a weight narrower than 3/4 of its 256-column tiles would leave the tile's columns empty)
     const bool wide_enough = 4 * N >= 3 * ceil_div(N, 256) * 256;
-    if (M > 128 && big_tiles >= 192 && wide_enough) return p;
+    const char* p256 = dev_switch("MIQ_GEMM_PLAN256");   // developer A/B switch: 0 = keep large problems off the 256 x 256 kernel
+    if (M > 128 && big_tiles >= 192 && wide_enough && !(p256 && p256[0] == '0')) return p;
     if (M <= 16) {   // one 16-row MFMA group: beyond it the activation re-reads cost more than tiles + split-K
         const char* sk = dev_switch("MIQ_GEMM_SKINNY");   // developer A/B switch: 0 = tiled kernels for small M too
         // ... unless the weight has enough 64-channel tiles to fill the chip without split-K: the 32-row ring
