@@ -323,6 +323,14 @@ __global__ __launch_bounds__(256) void gemm_w8f_any_kernel(const T* __restrict__
     }
 }
 
+// Deepest ring (at most four K-tiles) that fits the 160 KiB of LDS.  (Six- and eight-deep rings of the 16- and
+// 32-row tiles were measured: equal at best, up to 1.7x slower where they cost a second workgroup per CU.)
+constexpr int w8f_stages(int bm, int bn, int np) {
+    const int stage = (np * 2 * bm + bn) * kTileK;
+    const int fit = (160 * 1024) / stage;
+    return fit > 4 ? 4 : fit;
+}
+
 // Tile shape by M, from a measured sweep on the Llama-3-8B MLP weights ([14336,4096] and [4096,14336];
 // tools/w8f_sweep.py).  The bytes a launch moves from L2 into LDS are
 //     N*K * ceil(M / bm)  (weight)  +  planes * 2*M*K * ceil(N / bn)  (activation planes),
@@ -345,8 +353,13 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
         p.bm = planes == 2 ? 64 : 32; p.bn = planes == 2 ? 256 : 64;
     } else if (M <= 128) {
         p.bm = 32; p.bn = 256;
-    } else if (planes == 1 && ceil_div(M, 128) * ceil_div(N, 256) >= 200) {
-        p.bn = 256;   // one activation plane leaves LDS for a 256-channel tile: 900-1080 against 770-860 TFLOP/s
+    } else if (planes == 1 && N >= 512) {
+        // One activation plane leaves LDS for a 256-channel tile, which moves fewer bytes per flop (900-1080
+        // against 770-860 TFLOP/s at large M) but halves the tile count: take it when its rounds over the 256
+        // CUs (one workgroup per CU either way), priced at 0.8 of a 128 x 128 round per unit of area, come out
+        // shorter (M = 384 on [14336,4096]: 65 against 82 us; M = 256: 49 against 43 us).
+        const int64_t t128 = ceil_div(M, 128) * ceil_div(N, 128), t256 = ceil_div(M, 128) * ceil_div(N, 256);
+        if (1.6 * static_cast<double>(ceil_div(t256, 256)) < static_cast<double>(ceil_div(t128, 256))) p.bn = 256;
     }
     while (p.bm < 128 && p.bn > 64 && N < 2 * p.bn) p.bn >>= 1;   // narrow weights: no empty tile columns
     if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switches
@@ -360,9 +373,13 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
     }
     const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
     const int64_t nt = ceil_div(K, kTileK);
+    // Split-K for thin problems: as many slices as keep every workgroup resident at once (a slice more would
+    // start a second round on a few CUs: 288 workgroups took 97 us where 192 took 67).
+    const int64_t lds = static_cast<int64_t>(w8f_stages(p.bm, p.bn, planes)) * (planes * 2 * p.bm + p.bn) * kTileK;
+    const int64_t resident = 256 * std::min<int64_t>(2, (160 * 1024) / lds);
     int64_t splits = 1;
-    if (tiles < 160 && nt >= 16) {
-        splits = ceil_div(p.bm == 128 || p.bn > 64 ? 256 : 512, tiles);
+    if (tiles < 160 && nt >= 16) {   // (a grid that already covers most CUs once is left whole)
+        splits = resident / tiles;
         if (splits > nt / 4) splits = nt / 4;                // at least 4 K-tiles (512 of K) per slice
         if (splits > K / (8 * M)) splits = K / (8 * M);      // slab traffic (2 * 4*splits*M*N) <= weight bytes N*K
         if (splits > 32) splits = 32;
@@ -373,14 +390,6 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
         p.splits = static_cast<int>(ceil_div(nt, p.kt_per_split));
     }
     return p;
-}
-
-// Deepest ring (at most four K-tiles) that fits the 160 KiB of LDS.  (Six- and eight-deep rings of the 16- and
-// 32-row tiles were measured: equal at best, up to 1.7x slower where they cost a second workgroup per CU.)
-constexpr int w8f_stages(int bm, int bn, int np) {
-    const int stage = (np * 2 * bm + bn) * kTileK;
-    const int fit = (160 * 1024) / stage;
-    return fit > 4 ? 4 : fit;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT>
