@@ -206,124 +206,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     }
 }
 
-// Epilogue of a 256 x 256 tile held as acc[qm][qn][i][j] by 8 waves (2 x 4).  D[i][j] of a fragment:
-// i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
-//
-// bf16 outputs: a lane's four channels of one fragment are only 8 bytes, so the fragments j = 0, 1 of a
-// row group (channels 0-15 and 16-31 of the wave's 32) first trade 16-lane rows (pair_rows_bf16); every
-// lane then stores eight consecutive channels as one 16-byte vector: half the store instructions, and a
-// row's 32 channels leave as one 64-byte segment.
-template <int OUT, bool NT = true, bool WIDE16 = true>
-__device__ __forceinline__ void store_tile_256(const GemmArgs& g, const v4i (&acc)[2][2][4][2], int m0, int n0, int wm,
-                                               int wn, int lane) {
-    const bool vec_ok = (g.N & 3) == 0;
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn) {
-        const int nb = n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
-        float al[2][4], bi[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nb + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                al[j][e] = 1.f;
-                bi[j][e] = 0.f;
-                if constexpr (OUT != kOutI32) {
-                    if (n + e < g.N) {
-                        al[j][e] = g.alpha[n + e];
-                        if (g.bias) bi[j][e] = g.bias[n + e];
-                    }
-                }
-            }
-        }
-        if constexpr (OUT == kOutBF16 && WIDE16) {
-            if ((g.N & 7) == 0 && nb + 32 <= g.N) {   // wave-uniform
-                const int n = nb + paired_offset(lane);
-#pragma unroll
-                for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint2 p[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const v4i a = acc[qm][qn][i][j];
-                            p[j] = pack4_bf16(dequant1(a[0], bi[j][0], al[j][0], g.beta), dequant1(a[1], bi[j][1], al[j][1], g.beta),
-                                              dequant1(a[2], bi[j][2], al[j][2], g.beta), dequant1(a[3], bi[j][3], al[j][3], g.beta));
-                        }
-                        const v4i v = pair_rows_bf16(p[0], p[1]);
-                        const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
-                        if (m >= g.M) continue;
-                        v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) + static_cast<size_t>(m) * g.N + n);
-                        if constexpr (NT) {
-                            __builtin_nontemporal_store(v, o);
-                        } else {
-                            *o = v;
-                        }
-                    }
-                continue;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nb + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
-                    if (m >= g.M || n >= g.N) continue;
-                    const v4i a = acc[qm][qn][i][j];
-                    const size_t idx = static_cast<size_t>(m) * g.N + n;
-                    if constexpr (OUT == kOutI32) {
-                        int* o = static_cast<int*>(g.out) + idx;
-                        if (vec_ok && n + 3 < g.N) {
-                            if constexpr (NT) {
-                                __builtin_nontemporal_store(a, reinterpret_cast<v4i*>(o));
-                            } else {
-                                *reinterpret_cast<v4i*>(o) = a;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < g.N) o[e] = a[e];
-                        }
-                    } else {
-                        float y[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[j][e], al[j][e], g.beta);
-                        if constexpr (OUT == kOutF32) {
-                            float* o = static_cast<float*>(g.out) + idx;
-                            if (vec_ok && n + 3 < g.N) {
-                                // Nontemporal: the output is written once and read by a later kernel; kept
-                                // out of the caches it costs the operand stream nothing (8 % on 8192^3
-                                // when successive layers write different buffers).
-                                if constexpr (NT) {
-                                    __builtin_nontemporal_store(v4f{y[0], y[1], y[2], y[3]}, reinterpret_cast<v4f*>(o));
-                                } else {
-                                    *reinterpret_cast<v4f*>(o) = v4f{y[0], y[1], y[2], y[3]};
-                                }
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (n + e < g.N) o[e] = y[e];
-                            }
-                        } else {
-                            uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
-                            if (vec_ok && n + 3 < g.N) {
-                                // cached: as 8-byte nontemporal stores this epilogue ran 23 % slower (measured)
-                                *reinterpret_cast<uint2*>(o) = pack4_bf16(y[0], y[1], y[2], y[3]);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (n + e < g.N) o[e] = f32_to_bf16_bits(y[e]);
-                            }
-                        }
-                    }
-                }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // 256 x 256 tile, software-pipelined: the kernel large GEMMs run on.
 //

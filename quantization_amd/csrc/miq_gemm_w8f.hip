@@ -286,6 +286,187 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 256 x 256 tile, software-pipelined, one activation plane (bf16 activations): large M.
+//
+// The schedule of the int8 GEMM's 256 x 256 kernel (miq_gemm_i8.hip) carried over: 8 waves as 2 (m) x 4 (n),
+// a wave owns four 64 x 32 quadrants, a K-tile (here 64 elements) lives in LDS as four half-tiles X0 / X1
+// (activation rows 0-127 / 128-255, 128 bytes each = 16 KiB) and W0 / W1 (weight rows likewise, 64 bytes each
+// = 8 KiB), two K-tile buffers (96 KiB).  Per K-tile four phases of 16 MFMAs (one quadrant each); a phase is
+// LDS fragment reads (+ widening the weight bytes) and one half-tile of LDS-DMA for a later K-tile, a counted
+// vmcnt, a raw barrier, the MFMAs, a raw barrier:
+//   P1: read W0 of tile t    | DMA W1(t+1) | vmcnt(6) | barrier | MFMA quadrant (0,0) | barrier
+//   P2: read W1              | DMA X1(t+1) | vmcnt(6) | barrier | MFMA (0,1)          | barrier
+//   P3: read X1              | DMA X0(t+2) | vmcnt(6) | barrier | MFMA (1,1)          | barrier
+//   P4: read X0 of tile t+1  | DMA W0(t+2) | vmcnt(6) | barrier | MFMA (1,0)          | barrier
+// Waves 4-7 run one barrier behind waves 0-3.  Every wave issues two DMA instructions per X half-tile and one
+// per W half-tile, six per K-tile, so vmcnt(6) after a phase's issue means "the half-tile issued four phases
+// ago has landed"; the wait that retires a half-tile sits one barrier before its first read, and a half-tile
+// is re-staged at least two phases after its last read.
+//
+// A weight half-tile keeps TWO 64-byte weight rows per 128-byte LDS row (row pair j = n >> 1; the 16-byte
+// chunk c of row n is logical slot q = (n & 1) * 4 + c, stored at slot q ^ ((j >> 1) & 3)): a 16-lane group
+// of a fragment read then touches 16 different 16-byte slots of the 256-byte bank row, as the activation
+// reads do under the 128-byte-row swizzle.
+// ---------------------------------------------------------------------------------------
+#define MIQ_W8F_BARRIER()                   \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();       \
+        asm volatile("" ::: "memory");      \
+    } while (0)
+#define MIQ_W8F_WAIT_DMA() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+
+template <int OUT>
+__global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
+    constexpr int kXHalf = 128 * kTileK;            // 128 rows x 64 bf16
+    constexpr int kWHalf = 64 * kTileK;             // 128 rows x 64 int8 = 64 row pairs
+    constexpr int kBuf = 2 * kXHalf + 2 * kWHalf;   // X0 X1 W0 W1
+    constexpr int kStepK = 64;                      // elements per K-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const uint32_t kb = 2u * static_cast<uint32_t>(g.K);   // bytes per activation row
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, static_cast<uint32_t>(g.M) * kb);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+
+    // Staging.  X: a wave-instruction moves 8 rows x 128 B, two per half-tile and wave (row groups `wave` and
+    // `wave + 8`).  W: 8 row pairs x 128 B, one per half-tile and wave.
+    const int srow = wave * 8 + (lane >> 3);
+    const int xcbyte = ((lane & 7) ^ ((srow >> 1) & 7)) * kChunk;
+    const int wq = (lane & 7) ^ ((srow >> 1) & 3);           // logical slot this lane's LDS slot holds
+    const int wrow = 2 * srow + (wq >> 2), wcbyte = (wq & 3) * kChunk;
+    uint32_t xbase[2][2], wbase[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = m0 + h * 128 + srow + i * 64;
+            xbase[h][i] = r < g.M ? static_cast<uint32_t>(r) * kb + xcbyte : kOob;
+        }
+        const int n = n0 + h * 128 + wrow;
+        wbase[h] = n < g.N ? static_cast<uint32_t>(n) * g.K + wcbyte : kOob;
+    }
+    auto stage_x = [&](char* dst, const uint32_t (&base)[2], int kt) {
+        const uint32_t k = static_cast<uint32_t>(kt) * kTileK;
+        const bool k_ok = k + xcbyte < kb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(rx, dst + (wave + 8 * i) * (8 * kTileK), (k_ok && base[i] != kOob) ? base[i] + k : kOob);
+    };
+    auto stage_w = [&](char* dst, uint32_t base, int kt) {
+        const int k = kt * kStepK;
+        dma16(rw, dst + wave * (8 * kTileK), (k + wcbyte < g.K && base != kOob) ? base + k : kOob);
+    };
+
+    v4f acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (g.K + kStepK - 1) / kStepK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int xlo[2] = {fr * kTileK + (((2 * fq) ^ (fr >> 1)) * kChunk), fr * kTileK + (((2 * fq + 1) ^ (fr >> 1)) * kChunk)};
+    const int wlo = (fr >> 1) * kTileK + ((((fr & 1) * 4 + fq) ^ ((fr >> 2) & 3)) * kChunk);
+    const int x_frag = wm * 64 * kTileK;   // this wave's rows inside an X half-tile
+    const int w_frag = wn * 16 * kTileK;   // its 32 weight rows = 16 row pairs inside a W half-tile
+
+    char* const b0 = smem;
+    char* const b1 = smem + kBuf;
+    // Prologue: all of tile 0 plus X0 / W0 of tile 1; wait for X0(0), W0(0) only.
+    stage_x(b0, xbase[0], 0);
+    stage_w(b0 + 2 * kXHalf, wbase[0], 0);
+    stage_w(b0 + 2 * kXHalf + kWHalf, wbase[1], 0);
+    stage_x(b0 + kXHalf, xbase[1], 0);
+    stage_x(b1, xbase[0], 1);
+    stage_w(b1 + 2 * kXHalf, wbase[0], 1);
+    MIQ_W8F_WAIT_DMA();
+    MIQ_W8F_BARRIER();
+    if (wm == 1) MIQ_W8F_BARRIER();
+
+    v8bf xf[2][4], xf2[2][4], wf0[2][2], wf1[2][2];   // [k half][fragment]
+    auto read_w = [&](v8bf (&wf)[2][2], const char* half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const v4i raw = lds_read16(half + w_frag + j * 8 * kTileK + wlo);
+            wf[0][j] = int8x8_to_bf16(raw[0], raw[1]);
+            wf[1][j] = int8x8_to_bf16(raw[2], raw[3]);
+        }
+    };
+    auto read_x = [&](v8bf (&f)[2][4], const char* half) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[e][i] = __builtin_bit_cast(v8bf, lds_read16(half + x_frag + i * 16 * kTileK + xlo[e]));
+    };
+    auto mma = [&](v4f (&c)[4][2], const v8bf (&f)[2][4], const v8bf (&wf)[2][2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+    };
+
+    read_x(xf, b0);   // X0(0)
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * kBuf;
+        char* nxt = smem + ((t + 1) & 1) * kBuf;
+
+        read_w(wf0, cur + 2 * kXHalf);
+        stage_w(nxt + 2 * kXHalf + kWHalf, wbase[1], t + 1);
+        MIQ_W8F_WAIT_DMA();   // W1(t) has landed
+        MIQ_W8F_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        mma(acc[0][0], xf, wf0);
+        __builtin_amdgcn_s_setprio(0);
+        MIQ_W8F_BARRIER();
+
+        read_w(wf1, cur + 2 * kXHalf + kWHalf);
+        stage_x(nxt + kXHalf, xbase[1], t + 1);
+        MIQ_W8F_WAIT_DMA();   // X1(t)
+        MIQ_W8F_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        mma(acc[0][1], xf, wf1);
+        __builtin_amdgcn_s_setprio(0);
+        MIQ_W8F_BARRIER();
+
+        read_x(xf2, cur + kXHalf);
+        stage_x(cur, xbase[0], t + 2);
+        MIQ_W8F_WAIT_DMA();   // X0(t+1)
+        MIQ_W8F_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        mma(acc[1][1], xf2, wf1);
+        __builtin_amdgcn_s_setprio(0);
+        MIQ_W8F_BARRIER();
+
+        read_x(xf, nxt);      // X0(t+1): retired by the wait one phase ago
+        stage_w(cur + 2 * kXHalf, wbase[0], t + 2);
+        MIQ_W8F_WAIT_DMA();   // W0(t+1)
+        MIQ_W8F_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        mma(acc[1][0], xf2, wf0);
+        __builtin_amdgcn_s_setprio(0);
+        MIQ_W8F_BARRIER();
+    }
+    if (wm == 0) MIQ_W8F_BARRIER();   // every wave executes the same number of barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
+
+    store_tile_256<OUT>(g, acc, m0, n0, wm, wn, lane);
+}
+
 // Sums the split-K slabs and applies the epilogue.
 template <int OUT>
 __global__ __launch_bounds__(256) void w8f_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, W8fArgs g) {
@@ -354,12 +535,20 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
     } else if (M <= 128) {
         p.bm = 32; p.bn = 256;
     } else if (planes == 1 && N >= 512) {
-        // One activation plane leaves LDS for a 256-channel tile, which moves fewer bytes per flop (900-1080
-        // against 770-860 TFLOP/s at large M) but halves the tile count: take it when its rounds over the 256
-        // CUs (one workgroup per CU either way), priced at 0.8 of a 128 x 128 round per unit of area, come out
-        // shorter (M = 384 on [14336,4096]: 65 against 82 us; M = 256: 49 against 43 us).
-        const int64_t t128 = ceil_div(M, 128) * ceil_div(N, 128), t256 = ceil_div(M, 128) * ceil_div(N, 256);
-        if (1.6 * static_cast<double>(ceil_div(t256, 256)) < static_cast<double>(ceil_div(t128, 256))) p.bn = 256;
+        // One activation plane leaves LDS for wider tiles, which move fewer bytes per flop but come in fewer,
+        // longer rounds over the 256 CUs (one workgroup per CU in every case).  Measured time of a round,
+        // relative to a 128 x 128 round: 1.6 for 128 x 256 (twice the area) and 2.5 for the software-pipelined
+        // 256 x 256 kernel (four times the area): the shape with the least rounds x time runs (8192^3: 820 us
+        // on 256 x 256 against 1070 and 1290; M = 2048 on [4096,14336], 128 tiles of 256 x 256: 223 us on
+        // 128 x 256 against 285; M = 256 on [14336,4096]: 43 us on 128 x 128 against 49).
+        const double r128 = static_cast<double>(ceil_div(ceil_div(M, 128) * ceil_div(N, 128), 256));
+        const double r128x256 = 1.6 * static_cast<double>(ceil_div(ceil_div(M, 128) * ceil_div(N, 256), 256));
+        const double r256 = 2.5 * static_cast<double>(ceil_div(ceil_div(M, 256) * ceil_div(N, 256), 256));
+        if (r256 < r128 && r256 < r128x256) {
+            p.bm = 256; p.bn = 256;
+        } else if (r128x256 < r128) {
+            p.bn = 256;
+        }
     }
     while (p.bm < 128 && p.bn > 64 && N < 2 * p.bn) p.bn >>= 1;   // narrow weights: no empty tile columns
     if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switches
@@ -370,7 +559,9 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
         const int bn = atoi(t);
         if (p.bm < 128 && (bn == 64 || bn == 128 || bn == 256)) p.bn = bn;
         if (p.bm == 128 && planes == 1 && (bn == 128 || bn == 256)) p.bn = bn;
+        if (p.bm == 256 && planes == 1 && bn == 256) p.bn = bn;
     }
+    if (p.bm == 256 && p.bn == 256) return p;   // the pipelined kernel sums all of K
     const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
     const int64_t nt = ceil_div(K, kTileK);
     // Split-K for thin problems: as many slices as keep every workgroup resident at once (a slice more would
@@ -435,6 +626,16 @@ int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t 
         default: break;
     }
     if constexpr (NP == 1) {   // one activation plane leaves LDS for wider tiles
+        if (plan.bm == 256 && plan.bn == 256) {
+            W8fArgs a = g;
+            a.tiles_m = static_cast<int>(ceil_div(g.M, 256));
+            a.tiles_n = static_cast<int>(ceil_div(g.N, 256));
+            constexpr int kLds = 2 * (2 * 128 + 2 * 64) * kTileK;
+            auto kern = gemm_w8f_256_kernel<OUT>;
+            if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+            kern<<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+            return check_launch("gemm_w8f_256_kernel");
+        }
         if (plan.bm == 128 && plan.bn == 256) return launch_w8f_tile<128, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
         if (plan.bm == 256) return launch_w8f_tile<256, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
     }

@@ -170,6 +170,21 @@ def test_w8f_large_m_tiles(N, xdt):
     """M > 128 with enough 128 x 256 tiles to fill the chip (bf16 takes that tile), ragged in all three dimensions."""
     x, w, b, alpha = make(1300, 5000, 272, xdt, seed=21)
     check(N, x, w, b, alpha)
+    x, w, b, alpha = make(4100, 4100, 144, xdt, seed=22)   # enough 256 x 256 tiles for the pipelined kernel (bf16)
+    check(N, x, w, b, alpha)
+
+
+@pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (300, 520, 80), (1000, 777 * 4, 1040), (513, 260, 4096 + 48),
+                                    (2048, 2048, 2048), (256, 512, 16)])
+def test_w8f_pipelined_256_tile(N, M, Nn, K, monkeypatch):
+    """The software-pipelined 256 x 256 kernel (bf16 activations), forced through the developer switches so that
+    ragged edges in all three dimensions and one-tile problems reach it; each case runs three times on fresh
+    data (a staging race would show as a wrong tile in some run)."""
+    monkeypatch.setenv("MIQ_W8F_BM", "256")
+    monkeypatch.setenv("MIQ_W8F_BN", "256")
+    for rep in range(3):
+        x, w, b, alpha = make(M, Nn, K, "bf16", seed=31 * rep + M)
+        check(N, x, w, b, alpha, out_dtype=torch.float32 if rep < 2 else torch.bfloat16)
 
 
 def test_w8f_argument_checks(N):
