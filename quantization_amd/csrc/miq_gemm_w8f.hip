@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
     } while (0)
 #define MIQ_W8F_WAIT_DMA() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 
-template <int OUT>
+template <int OUT, int NP>
 __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
     constexpr int kXHalf = 128 * kTileK;            // 128 rows x 64 bf16
     constexpr int kWHalf = 64 * kTileK;             // 128 rows x 64 int8 = 64 row pairs
@@ -334,9 +334,11 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
     const int m0 = tm * 256, n0 = tn * 256;
 
     const uint32_t kb = 2u * static_cast<uint32_t>(g.K);   // bytes per activation row
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, static_cast<uint32_t>(g.M) * kb);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, (NP - 1) * g.plane_stride + static_cast<uint32_t>(g.M) * kb);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
 
+    // Two activation planes (fp32 / fp16 activations): the loop walks 2 * ceil(K / 64) K-tiles, tile u pairing
+    // plane u & 1 with the weight's K-tile u >> 1 (the weight half-tiles are staged once per plane).
     // Staging.  X: a wave-instruction moves 8 rows x 128 B, two per half-tile and wave (row groups `wave` and
     // `wave + 8`).  W: 8 row pairs x 128 B, one per half-tile and wave.
     const int srow = wave * 8 + (lane >> 3);
@@ -355,13 +357,14 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
         wbase[h] = n < g.N ? static_cast<uint32_t>(n) * g.K + wcbyte : kOob;
     }
     auto stage_x = [&](char* dst, const uint32_t (&base)[2], int kt) {
-        const uint32_t k = static_cast<uint32_t>(kt) * kTileK;
+        const uint32_t k = static_cast<uint32_t>(NP == 2 ? kt >> 1 : kt) * kTileK;
         const bool k_ok = k + xcbyte < kb;
+        const uint32_t pk = k + (NP == 2 ? (kt & 1) * g.plane_stride : 0u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rx, dst + (wave + 8 * i) * (8 * kTileK), (k_ok && base[i] != kOob) ? base[i] + k : kOob);
+        for (int i = 0; i < 2; ++i) dma16(rx, dst + (wave + 8 * i) * (8 * kTileK), (k_ok && base[i] != kOob) ? base[i] + pk : kOob);
     };
     auto stage_w = [&](char* dst, uint32_t base, int kt) {
-        const int k = kt * kStepK;
+        const int k = (NP == 2 ? kt >> 1 : kt) * kStepK;
         dma16(rw, dst + wave * (8 * kTileK), (k + wcbyte < g.K && base != kOob) ? base + k : kOob);
     };
 
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.K + kStepK - 1) / kStepK;
+    const int nt = NP * ((g.K + kStepK - 1) / kStepK);
     const int fr = lane & 15, fq = lane >> 4;
     const int xlo[2] = {fr * kTileK + (((2 * fq) ^ (fr >> 1)) * kChunk), fr * kTileK + (((2 * fq + 1) ^ (fr >> 1)) * kChunk)};
     const int wlo = (fr >> 1) * kTileK + ((((fr & 1) * 4 + fq) ^ ((fr >> 2) & 3)) * kChunk);
@@ -550,17 +553,25 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
             p.bn = 256;
         }
     }
+    if (planes == 2 && M > 128 && N >= 512) {
+        // Two planes: the pipelined 256 x 256 kernel walks them as 2 * K / 64 K-tiles; a round of it takes 2.9
+        // rounds of 128 x 128 tiles (8192^3: 1705 against 2290 us; 128 tiles on [4096,14336]: 605 against 500).
+        const double r128 = static_cast<double>(ceil_div(ceil_div(M, 128) * ceil_div(N, 128), 256));
+        const double r256 = 2.9 * static_cast<double>(ceil_div(ceil_div(M, 256) * ceil_div(N, 256), 256));
+        if (r256 < r128) { p.bm = 256; p.bn = 256; }
+    }
     while (p.bm < 128 && p.bn > 64 && N < 2 * p.bn) p.bn >>= 1;   // narrow weights: no empty tile columns
     if (const char* t = dev_switch("MIQ_W8F_BM")) {   // developer A/B switches
         const int bm = atoi(t);
-        if (bm == 16 || bm == 32 || bm == 64 || bm == 128 || (bm == 256 && planes == 1)) { p.bm = bm; p.bn = bm >= 128 ? 128 : 64; }
+        if (bm == 16 || bm == 32 || bm == 64 || bm == 128 || bm == 256) { p.bm = bm; p.bn = bm >= 128 ? 128 : 64; }
     }
     if (const char* t = dev_switch("MIQ_W8F_BN")) {
         const int bn = atoi(t);
         if (p.bm < 128 && (bn == 64 || bn == 128 || bn == 256)) p.bn = bn;
         if (p.bm == 128 && planes == 1 && (bn == 128 || bn == 256)) p.bn = bn;
-        if (p.bm == 256 && planes == 1 && bn == 256) p.bn = bn;
+        if (p.bm == 256 && bn == 256) p.bn = bn;
     }
+    if (p.bm == 256) p.bn = 256;
     if (p.bm == 256 && p.bn == 256) return p;   // the pipelined kernel sums all of K
     const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
     const int64_t nt = ceil_div(K, kTileK);
@@ -625,19 +636,18 @@ int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t 
         case 64256: return launch_w8f_tile<64, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
         default: break;
     }
+    if (plan.bm == 256 && plan.bn == 256) {
+        W8fArgs a = g;
+        a.tiles_m = static_cast<int>(ceil_div(g.M, 256));
+        a.tiles_n = static_cast<int>(ceil_div(g.N, 256));
+        constexpr int kLds = 2 * (2 * 128 + 2 * 64) * kTileK;
+        auto kern = gemm_w8f_256_kernel<OUT, NP>;
+        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+        kern<<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+        return check_launch("gemm_w8f_256_kernel");
+    }
     if constexpr (NP == 1) {   // one activation plane leaves LDS for wider tiles
-        if (plan.bm == 256 && plan.bn == 256) {
-            W8fArgs a = g;
-            a.tiles_m = static_cast<int>(ceil_div(g.M, 256));
-            a.tiles_n = static_cast<int>(ceil_div(g.N, 256));
-            constexpr int kLds = 2 * (2 * 128 + 2 * 64) * kTileK;
-            auto kern = gemm_w8f_256_kernel<OUT>;
-            if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
-            kern<<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
-            return check_launch("gemm_w8f_256_kernel");
-        }
         if (plan.bm == 128 && plan.bn == 256) return launch_w8f_tile<128, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
-        if (plan.bm == 256) return launch_w8f_tile<256, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
     }
     return launch_w8f_tile<128, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
 }

@@ -176,14 +176,15 @@ def test_w8f_large_m_tiles(N, xdt):
 
 @pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (300, 520, 80), (1000, 777 * 4, 1040), (513, 260, 4096 + 48),
                                     (2048, 2048, 2048), (256, 512, 16)])
-def test_w8f_pipelined_256_tile(N, M, Nn, K, monkeypatch):
-    """The software-pipelined 256 x 256 kernel (bf16 activations), forced through the developer switches so that
+@pytest.mark.parametrize("xdt", ["bf16", "f32", "f16"])
+def test_w8f_pipelined_256_tile(N, M, Nn, K, xdt, monkeypatch):
+    """The software-pipelined 256 x 256 kernel (one or two activation planes), forced through the developer switches so that
     ragged edges in all three dimensions and one-tile problems reach it; each case runs three times on fresh
     data (a staging race would show as a wrong tile in some run)."""
     monkeypatch.setenv("MIQ_W8F_BM", "256")
     monkeypatch.setenv("MIQ_W8F_BN", "256")
     for rep in range(3):
-        x, w, b, alpha = make(M, Nn, K, "bf16", seed=31 * rep + M)
+        x, w, b, alpha = make(M, Nn, K, xdt, seed=31 * rep + M)
         check(N, x, w, b, alpha, out_dtype=torch.float32 if rep < 2 else torch.bfloat16)
 
 
