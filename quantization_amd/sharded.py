@@ -49,6 +49,7 @@ class ColumnShardedLinear:
         self.out_dtype = out_dtype
         self.n_max = -(-out_features // self.world)
         self._gemm = gemm or _native.gemm_i8
+        self._custom_gemm = gemm is not None
 
     @classmethod
     def from_float(cls, weight, bias=None, group=None, out_dtype=torch.float32, gemm=None, quantize=None):
@@ -63,8 +64,11 @@ class ColumnShardedLinear:
         return cls(q, scale, b, n, group=group, out_dtype=out_dtype, gemm=gemm)
 
     def local_forward(self, x):
-        """out[:, lo:hi] for int8 activations x [M, K] (replicated on every rank)."""
-        return self._gemm(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype)
+        """out[:, lo:hi] for activations x [M, K] replicated on every rank: int8 (int8 product) or floating point
+        (the weight-only product on the int8 weight as stored)."""
+        if self._custom_gemm or x.dtype == torch.int8:
+            return self._gemm(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype)
+        return _native.gemm_w8(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype)
 
     def gather_async(self, y_local):
         """Start the all-gather of the ranks' column blocks.  Returns (buffer [g, M, n_max], work)."""

@@ -188,6 +188,53 @@ def test_w8f_pipelined_256_tile(N, M, Nn, K, xdt, monkeypatch):
         check(N, x, w, b, alpha, out_dtype=torch.float32 if rep < 2 else torch.bfloat16)
 
 
+def test_sharded_layer_takes_float_and_int8_activations(N):
+    """ColumnShardedLinear on one GPU (world size 1: the layer owns every row): int8 activations give the int8
+    product, floating-point activations the weight-only product, both equal to the unsharded calls."""
+    from quantization_amd.sharded import ColumnShardedLinear
+    g = torch.Generator().manual_seed(4)
+    w = (torch.randn(200, 320, generator=g) * 0.05).cuda()
+    b = torch.randn(200, generator=g).cuda()
+    layer = ColumnShardedLinear.from_float(w, b)
+    q, scale, _ = N.quantize_rows_sym_i8(w)
+    xi = torch.randint(-128, 128, (9, 320), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    assert torch.equal(layer(xi), N.gemm_i8(xi, q, bias=b, alpha=scale))
+    for dt in (torch.float32, torch.bfloat16):
+        xf = torch.randn(9, 320, generator=g).to(dt).cuda()
+        assert torch.equal(layer(xf), N.gemm_w8(xf, q, bias=b, alpha=scale))
+
+
+def test_launches_capture_into_a_hip_graph(N):
+    """Nothing in the library allocates or synchronises: an int8 GEMM and a weight-only GEMM captured into one
+    graph replay to the eager results, also after the inputs change in place."""
+    g = torch.Generator().manual_seed(8)
+    w = torch.randint(-128, 128, (384, 512), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    alpha = (torch.rand(384, generator=g) * 0.01).cuda()
+    xi = torch.randint(-128, 128, (24, 512), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    xf = torch.randn(24, 512, generator=g).cuda()
+    oi, of = torch.empty(24, 384).cuda(), torch.empty(24, 384).cuda()
+
+    def step():
+        N.gemm_i8(xi, w, alpha=alpha, out=oi)
+        N.gemm_w8(xf, w, alpha=alpha, out=of)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    xi.copy_(torch.randint(-128, 128, (24, 512), generator=g, dtype=torch.int32).to(torch.int8))
+    xf.copy_(torch.randn(24, 512, generator=g))
+    graph.replay()
+    torch.cuda.synchronize()
+    gi, gf = oi.clone(), of.clone()
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(gi, oi) and torch.equal(gf, of)
+
+
 def test_w8f_argument_checks(N):
     x = torch.randn(4, 32).cuda()
     w = torch.zeros(8, 32, dtype=torch.int8).cuda()
