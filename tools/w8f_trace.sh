@@ -11,4 +11,5 @@ for case in "16 f32" "16 bf16" "64 f32" "64 bf16" "128 f32" "128 bf16" "256 f32"
   echo "M=$1 $2 [14336,4096]"
   python3 $R/tools/prof_kernels.py $(find $out/m$1_$2 -name "*.db" | head -1) w8f
   python3 $R/tools/prof_kernels.py $(find $out/m$1_$2 -name "*.db" | head -1) split_planes
+  rm -rf $out/m$1_$2
 done
