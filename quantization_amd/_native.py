@@ -89,9 +89,31 @@ def require_device(t, name):
         raise RuntimeError(f"{name} must be contiguous")
 
 
+class _on:
+    """Makes `device` current for the duration of a call; free when it already is (the usual case:
+    torch.cuda.device() costs several microseconds per entry, a decode-size kernel ~15)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx, self.prev = device.index, None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and self.idx != cur:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _f32_vec(t, n, name, device):
     if t is None:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous() and t.numel() == n:
+        return t   # only its address is used: any dense shape with n elements will do
     t = t.detach().reshape(-1)
     if t.numel() != n:
         raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
@@ -111,7 +133,7 @@ def quantize_rows_sym_i8(w, want_row_max=False):
     scale = torch.empty(rows, dtype=torch.float32, device=w.device)
     zp = torch.empty(rows, dtype=torch.int64, device=w.device)
     row_max = torch.empty(rows, dtype=torch.float32, device=w.device) if want_row_max else None
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _check(lib().miq_quantize_rows_sym_i8(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(q), _ptr(scale),
                                               _ptr(zp), _ptr(row_max), _stream()))
     return (q, scale, zp, row_max) if want_row_max else (q, scale, zp)
@@ -123,7 +145,7 @@ def row_max(w):
     rows = w.shape[0]
     cols = w.numel() // rows if rows else 0
     out = torch.empty(rows, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _check(lib().miq_row_max(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(out), _stream()))
     return out
 
@@ -142,7 +164,7 @@ def quantize_rows_given_i8(w, scale, zp=None):
         if zp.numel() != scale.numel():
             raise RuntimeError("zero_point and scales must have the same number of entries")
     q = torch.empty(w.shape, dtype=torch.int8, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _check(lib().miq_quantize_rows_given_i8(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(scale), _ptr(zp),
                                                 per_row, _ptr(q), _stream()))
     return q
@@ -157,7 +179,7 @@ def dequantize_channels_f32(y, scale, zp=None):
     scale = _f32_vec(scale, channels, "scales", y.device)
     zp = _f32_vec(zp, channels, "zero_point", y.device)
     out = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _check(lib().miq_dequantize_channels_f32(_ptr(y), _ptr(scale), _ptr(zp), outer, channels, inner, _ptr(out),
                                                  _stream()))
     return out
@@ -171,7 +193,7 @@ def dequantize_rows_i8(q, scale, zp=None):
     if zp is not None:
         zp = zp.detach().reshape(-1).to(device=q.device, dtype=torch.int64).contiguous()
     out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _check(lib().miq_dequantize_rows_i8(_ptr(q), _ptr(scale), _ptr(zp), rows, cols, _ptr(out), _stream()))
     return out
 
@@ -180,7 +202,7 @@ def transpose_i8(src):
     require_device(src, "src")
     rows, cols = src.shape
     dst = torch.empty((cols, rows), dtype=torch.int8, device=src.device)
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         _check(lib().miq_transpose_i8(_ptr(src), rows, cols, _ptr(dst), _stream()))
     return dst
 
@@ -194,7 +216,7 @@ def tensor_minmax(x):
     out = torch.empty(2, dtype=torch.float32, device=x.device)
     need = lib().miq_tensor_minmax_workspace(n)
     ws = torch.empty(max(need, 4), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().miq_tensor_minmax(_ptr(x), _FLOAT_CODES[x.dtype], n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
 
@@ -210,7 +232,7 @@ def dynamic_epilogue_i8(min_max, w_scale, bias, w_rowsum):
         bias = bias.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
     out = torch.empty(2 + 2 * n, dtype=torch.float32, device=dev)
     scale_zp, alpha, corr = out[:2], out[2:2 + n], out[2 + n:]
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().miq_dynamic_epilogue_i8(_ptr(min_max), _ptr(w_scale), _ptr(bias), _ptr(w_rowsum), n, _ptr(scale_zp),
                                              _ptr(alpha), _ptr(corr), _stream()))
     return scale_zp, alpha, corr
@@ -235,7 +257,7 @@ def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):
     if H + 2 * ph < kh or W + 2 * pw < kw:
         raise RuntimeError("pooling window larger than the padded input")
     out = torch.empty((B, C, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1), dtype=torch.int8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().miq_pool2d_to_i8(_ptr(x), code, B, C, H, W, kh, kw, sh, sw, ph, pw,
                                       MIQ_POOL_MAX if mode == "max" else MIQ_POOL_AVG, _ptr(out), _stream()))
     return out
@@ -269,7 +291,7 @@ def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=
     L = lib()
     need = L.miq_gemm_i8_workspace(w_layout, M, N, K)
     ws = torch.empty(need, dtype=torch.int8, device=a.device) if need else None
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _check(L.miq_gemm_i8(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
                              _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
     return out
@@ -304,7 +326,7 @@ def gemm_w8(x, w, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=
     code = _FLOAT_CODES[x.dtype]
     need = L.miq_gemm_w8_workspace(code, M, N, K)
     ws = torch.empty(need, dtype=torch.int8, device=x.device) if need else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(L.miq_gemm_w8(_ptr(x), code, _ptr(w), M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
                              _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
     return out
@@ -335,7 +357,7 @@ def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
     L = lib()
     need = L.miq_conv2d_i8_workspace(B, C, H, W, Co, KH, KW, stride, padding)
     ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(L.miq_conv2d_i8(_ptr(x), _ptr(w), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
                                float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
     return out
@@ -350,7 +372,7 @@ def epilogue_channels_f32(y, bias, alpha, beta=0.0):
     bias = _f32_vec(bias, channels, "bias", y.device)
     alpha = _f32_vec(alpha, channels, "alpha", y.device)
     out = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _check(lib().miq_epilogue_channels_f32(_ptr(y), _ptr(bias), _ptr(alpha), float(beta), outer, channels,
                                                inner, _ptr(out), _stream()))
     return out
