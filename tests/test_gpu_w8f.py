@@ -235,6 +235,22 @@ def test_launches_capture_into_a_hip_graph(N):
     assert torch.equal(gi, oi) and torch.equal(gf, of)
 
 
+def test_w8f_random_shapes(N):
+    """120 random (M, N, K, dtype, bias, out dtype) problems across every tile the plan can pick."""
+    import random
+    rnd = random.Random(2024)
+    for i in range(120):
+        M = rnd.choice([rnd.randint(1, 16), rnd.randint(17, 64), rnd.randint(65, 128), rnd.randint(129, 700)])
+        Nn = rnd.choice([rnd.randint(1, 63), rnd.randint(64, 600), rnd.randint(601, 1800)])
+        K = 16 * rnd.randint(1, 180)
+        if rnd.random() < 0.1:
+            K += rnd.randint(1, 15)      # scalar kernel
+        xdt = rnd.choice(["f32", "f16", "bf16"])
+        x, w, b, alpha = make(M, Nn, K, xdt, seed=1000 + i, bias=rnd.random() < 0.7)
+        check(N, x, w, b, alpha, beta=rnd.choice([0.0, 1.5]),
+              out_dtype=torch.bfloat16 if rnd.random() < 0.25 else torch.float32)
+
+
 def test_w8f_argument_checks(N):
     x = torch.randn(4, 32).cuda()
     w = torch.zeros(8, 32, dtype=torch.int8).cuda()
