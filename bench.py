@@ -271,7 +271,10 @@ def main():
                 "kernel": "gemm_i8_256_kernel",
                 "kernel_ms": round(k_ms, 4),
                 "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch; "
-                        "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/",
+                        "traffic = bytes per launch through the L2 <-> fabric ports from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in "
+                        "profiles/ (an upper bound of HBM bytes: it counts the fills of the eight per-XCD L2s, 8 XCDs x 4 rounds "
+                        "x 12 operand panels x 2 MiB = 768 MiB of first touches per launch, most of which the 256 MiB Infinity "
+                        "Cache serves; the operands themselves are 128 MiB, the output 256 MiB)",
             },
             "extra": {
                 "quantizer": {
