@@ -251,6 +251,22 @@ def test_w8f_random_shapes(N):
               out_dtype=torch.bfloat16 if rnd.random() < 0.25 else torch.float32)
 
 
+@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+@pytest.mark.parametrize("M,Nn,K", [(8192, 8192, 8192), (256, 14336, 4096), (16, 4096, 14336)])
+def test_w8f_full_size_equals_the_int8_product(N, M, Nn, K, xdt):
+    """Full BASELINE sizes, every element: on small integer activations (|x| <= 8, so every partial sum stays below
+    2^24 and fp32 accumulation is exact in any order) the weight-only kernel must reproduce the int8 GEMM's exact
+    int32 sums, epilogue included."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xi = torch.randint(-8, 9, (M, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
+    w = torch.randint(-128, 128, (Nn, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
+    alpha = torch.rand(Nn, generator=g, device="cuda") * 0.01 + 1e-4
+    bias = torch.randn(Nn, generator=g, device="cuda")
+    ref = N.gemm_i8(xi, w, bias=bias, alpha=alpha)
+    y = N.gemm_w8(xi.to(DT[xdt]), w, bias=bias, alpha=alpha)
+    assert torch.equal(y, ref)
+
+
 def test_w8f_argument_checks(N):
     x = torch.randn(4, 32).cuda()
     w = torch.zeros(8, 32, dtype=torch.int8).cuda()
