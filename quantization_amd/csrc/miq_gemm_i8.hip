@@ -844,8 +844,27 @@ namespace {
 size_t transposed_bytes(int w_layout, int64_t N, int64_t K) {
     return w_layout == MIQ_W_KN ? static_cast<size_t>(miq::round_up(N * K, 256)) : 0;
 }
+// A tile count a little over whole rounds of the 256 CUs costs the 256 x 256 kernel a whole extra round (288 tiles
+// take as long as 384: 169 against 104 us for 256).  Such problems are cut along M: the tile rows that make whole
+// rounds run on the 256 x 256 kernel, the few remaining rows as a second, small problem on the thin-tile kernels
+// (2304 x 8192 x 8192: 169 -> 136 us).  Returns the rows of the first part, M when the problem stays whole.
+int64_t rows_in_whole_rounds(int64_t M, int64_t N, int64_t K) {
+    if (plan_gemm(M, N, K).bm != 256) return M;
+    const char* sw = miq::dev_switch("MIQ_GEMM_ROWSPLIT");   // developer A/B switch: 0 = never cut
+    if (sw && sw[0] == '0') return M;
+    const int64_t tn = miq::ceil_div(N, 256), tm = miq::ceil_div(M, 256), tiles = tm * tn;
+    if (tiles <= 256 || tiles % 256 == 0) return M;
+    const int64_t tm_main = (tiles / 256) * 256 / tn;   // tile rows inside the whole rounds
+    if (tm_main < 1 || tm_main >= tm) return M;
+    const int64_t main_tiles = tm_main * tn, tail_tiles = miq::ceil_div(M - tm_main * 256, 256) * tn;
+    if (main_tiles % 256 != 0 && main_tiles % 256 < 200) return M;   // the rounds kept must be (nearly) full
+    if (tail_tiles > 96) return M;                                   // ... and the rest small against a round
+    return tm_main * 256;
+}
 size_t slab_bytes(int64_t M, int64_t N, int64_t K) {
     if (K % 16 != 0) return 0;
+    const int64_t m_main = rows_in_whole_rounds(M, N, K);
+    if (m_main < M) M -= m_main;   // only the second part can need slabs
     const GemmPlan p = plan_gemm(M, N, K);
     return p.splits > 1 ? static_cast<size_t>(miq::round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
 }
@@ -898,12 +917,25 @@ extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64
     const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
     const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(A, 16) && miq::aligned(W, 16) && out_vec_ok &&
                          (out_dtype == MIQ_I32 || (miq::aligned(alpha, 4) && miq::aligned(bias, 4)));
-    switch (out_dtype) {
-        case MIQ_F32:
-            return launch<kOutF32>(g, mfma_ok, slabs, st);
-        case MIQ_BF16:
-            return launch<kOutBF16>(g, mfma_ok, slabs, st);
-        default:
-            return launch<kOutI32>(g, mfma_ok, slabs, st);
+    auto run = [&](const GemmArgs& part, int* part_slabs) {
+        switch (out_dtype) {
+            case MIQ_F32:
+                return launch<kOutF32>(part, mfma_ok, part_slabs, st);
+            case MIQ_BF16:
+                return launch<kOutBF16>(part, mfma_ok, part_slabs, st);
+            default:
+                return launch<kOutI32>(part, mfma_ok, part_slabs, st);
+        }
+    };
+    const int64_t m_main = mfma_ok ? rows_in_whole_rounds(M, N, K) : M;
+    if (m_main < M) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
+        GemmArgs head = g, tail = g;
+        head.M = static_cast<int>(m_main);
+        if (int rc = run(head, nullptr)) return rc;
+        tail.A = A + m_main * K;
+        tail.out = static_cast<char*>(out) + static_cast<size_t>(m_main) * N * esz;
+        tail.M = static_cast<int>(M - m_main);
+        return run(tail, slabs);
     }
+    return run(g, slabs);
 }

@@ -412,3 +412,25 @@ def test_pool_rejects_bad_arguments():
         N.pool2d_to_i8(x, 7, 1, 0, "max")
     with pytest.raises(RuntimeError, match="must be float32"):
         N.pool2d_to_i8(x.double(), 2, 2, 0, "max")
+
+
+# ------------------------------------------------------------------------------ GEMM cut along M
+@pytest.mark.parametrize("M,Nn,K", [(2304, 8192, 272), (2100, 8192, 64), (4352, 8192, 128), (1280, 14336, 144),
+                                    (2304, 8190, 96)])
+@pytest.mark.parametrize("od", [torch.int32, torch.float32, torch.bfloat16])
+def test_gemm_whole_rounds_plus_tail(N, M, Nn, K, od, monkeypatch):
+    """Tile counts a little over a multiple of the 256 CUs run as whole rounds of 256 x 256 tiles plus a second
+    launch for the remaining rows: the result must equal the uncut run bit for bit, and the exact product."""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
+    w = torch.randint(-128, 128, (Nn, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
+    alpha = torch.rand(Nn, generator=g, device="cuda") * 0.01 + 1e-4
+    bias = torch.randn(Nn, generator=g, device="cuda")
+    kw = {} if od == torch.int32 else {"alpha": alpha, "bias": bias}
+    y = N.gemm_i8(a, w, out_dtype=od, **kw)
+    monkeypatch.setenv("MIQ_GEMM_ROWSPLIT", "0")
+    y0 = N.gemm_i8(a, w, out_dtype=od, **kw)
+    assert torch.equal(y, y0)
+    if od == torch.int32:
+        ref = (a.double() @ w.double().t()).to(torch.int32)      # |sum| < 2^53: exact
+        assert torch.equal(y, ref)
