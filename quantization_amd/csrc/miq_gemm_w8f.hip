@@ -663,8 +663,24 @@ int launch_any(const void* x, const W8fArgs& g, hipStream_t st) {
 size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
     return x_dtype == MIQ_BF16 ? 0 : static_cast<size_t>(round_up(M * K * 2, 256));
 }
+// As for the int8 GEMM: a count of 256 x 256 tiles a little over whole rounds of the 256 CUs is cut along M into
+// the whole rounds (pipelined kernel) and a small second problem.  Returns the rows of the first part, or M.
+int64_t w8f_rows_in_whole_rounds(int64_t M, int64_t N, int64_t K, int planes) {
+    const char* sw = dev_switch("MIQ_W8F_ROWSPLIT");   // developer A/B switch: 0 = never cut
+    if ((sw && sw[0] == '0') || M <= 256 || N < 512) return M;
+    const int64_t tn = ceil_div(N, 256), tm = ceil_div(M, 256), tiles = tm * tn;
+    if (tiles <= 256 || tiles % 256 == 0) return M;
+    const int64_t tm_main = (tiles / 256) * 256 / tn;
+    if (tm_main < 1 || tm_main >= tm) return M;
+    const int64_t main_tiles = tm_main * tn, tail_tiles = ceil_div(M - tm_main * 256, 256) * tn;
+    if ((main_tiles % 256 != 0 && main_tiles % 256 < 200) || tail_tiles > 96) return M;
+    const W8fPlan head = plan_w8f(tm_main * 256, N, K, planes);
+    return head.bm == 256 ? tm_main * 256 : M;   // only where the whole rounds do run on the pipelined kernel
+}
 size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K, int planes) {
     if (K % 16 != 0) return 0;
+    const int64_t m_main = w8f_rows_in_whole_rounds(M, N, K, planes);
+    if (m_main < M) M -= m_main;   // only the second part can need slabs
     const W8fPlan p = plan_w8f(M, N, K, planes);
     return p.splits > 1 ? static_cast<size_t>(round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
 }
@@ -732,7 +748,21 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
         if (int rc = check_launch("split_planes_kernel")) return rc;
         g.X = hi;
         g.plane_stride = static_cast<uint32_t>(pb);
-        return out_dtype == MIQ_F32 ? launch_w8f<2, kOutF32>(g, plan, slabs, st) : launch_w8f<2, kOutBF16>(g, plan, slabs, st);
     }
-    return out_dtype == MIQ_F32 ? launch_w8f<1, kOutF32>(g, plan, slabs, st) : launch_w8f<1, kOutBF16>(g, plan, slabs, st);
+    auto run = [&](const W8fArgs& part, const W8fPlan& pl) {
+        if (planes == 2)
+            return out_dtype == MIQ_F32 ? launch_w8f<2, kOutF32>(part, pl, slabs, st) : launch_w8f<2, kOutBF16>(part, pl, slabs, st);
+        return out_dtype == MIQ_F32 ? launch_w8f<1, kOutF32>(part, pl, slabs, st) : launch_w8f<1, kOutBF16>(part, pl, slabs, st);
+    };
+    const int64_t m_main = w8f_rows_in_whole_rounds(M, N, K, planes);
+    if (m_main < M) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
+        W8fArgs head = g, tail = g;
+        head.M = static_cast<int>(m_main);
+        if (int rc = run(head, plan_w8f(m_main, N, K, planes))) return rc;
+        tail.X = static_cast<const char*>(g.X) + m_main * K * 2;
+        tail.out = static_cast<char*>(out) + static_cast<size_t>(m_main) * N * esz;
+        tail.M = static_cast<int>(M - m_main);
+        return run(tail, plan_w8f(M - m_main, N, K, planes));
+    }
+    return run(g, plan);
 }

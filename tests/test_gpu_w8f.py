@@ -267,6 +267,16 @@ def test_w8f_full_size_equals_the_int8_product(N, M, Nn, K, xdt):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+@pytest.mark.parametrize("M,Nn,K", [(2304, 8192, 80), (2100, 8192, 144), (4400, 8190, 64)])
+def test_w8f_whole_rounds_plus_tail(N, M, Nn, K, xdt):
+    """A count of 256 x 256 tiles a little over whole rounds of the CUs runs as the whole rounds plus a second launch
+    for the remaining rows (both into the same output)."""
+    assert N.lib().miq_gemm_w8_workspace(2, M, Nn, K) >= 0
+    x, w, b, alpha = make(M, Nn, K, xdt, seed=M)
+    check(N, x, w, b, alpha)
+
+
 def test_w8f_argument_checks(N):
     x = torch.randn(4, 32).cuda()
     w = torch.zeros(8, 32, dtype=torch.int8).cuda()
