@@ -143,6 +143,23 @@ int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t 
                 const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight-only Conv2d on floating-point activations, NCHW in, OIHW int8 weights, NCHW out:
+ *       out[b,o,y,x] = (sum_{c,i,j} x[b,c,y*s+i-p,x*s+j-p] * float(w[o,c,i,j]) + bias[o]) * alpha[o] + beta
+ *
+ * Replaces the weight-only Quantizer.forward for nn.Conv2d (quant/Weight_Only/Quantizer.py:72-91):
+ * `weight.to(x.dtype)`, F.conv2d(x, ., stride, padding), `+ bias`, Qop.dequantize.  An implicit GEMM on the bf16
+ * MFMA with the activation carried as bf16 planes exactly as in miq_gemm_w8 (fp32-accurate); dilation 1,
+ * groups 1, one stride and one padding for both axes, zero padding.  Output size as F.conv2d:
+ * Ho = (H + 2*pad - KH) / stride + 1.
+ * workspace: at least miq_conv2d_w8_workspace(...) bytes, 256-byte aligned (padded channels-last planes of x
+ * and the re-laid weight). */
+size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                               int64_t KW, int64_t stride, int64_t pad);
+int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                  int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                  const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* dst[c,r] = src[r,c] for an int8 matrix src[rows, cols] (both dense).  Used to turn the
  * [K,N] weight of linear_w8a8 into the [N,K] layout once, ahead of repeated GEMMs. */
 int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream);

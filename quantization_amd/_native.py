@@ -39,6 +39,8 @@ SYMBOLS = {
     "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_gemm_w8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_w8": (_int, [_p, _int, _p, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_conv2d_w8_workspace": (_size, [_int] + [_i64] * 9),
+    "miq_conv2d_w8": (_int, [_p, _int, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
@@ -329,6 +331,42 @@ def gemm_w8(x, w, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=
     with _on(x.device):
         _check(L.miq_gemm_w8(_ptr(x), code, _ptr(w), M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
                              _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out
+
+
+def conv2d_w8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
+    """Weight-only Conv2d: floating-point NCHW x (fp32 / fp16 / bf16), int8 OIHW w, per-channel (acc + bias) * alpha + beta."""
+    require_device(x, "input")
+    require_device(w, "kernel")
+    if x.dtype not in _FLOAT_CODES or w.dtype != torch.int8:
+        raise RuntimeError(f"input must be fp32/fp16/bf16 and kernel int8 (got {x.dtype}, {w.dtype})")
+    if x.dim() != 4 or w.dim() != 4 or x.shape[1] != w.shape[1]:
+        raise RuntimeError(f"expected NCHW input and OIHW kernel with equal channels, got {tuple(x.shape)} and {tuple(w.shape)}")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    if alpha is None:
+        raise RuntimeError("alpha (the per-channel scale) is required")
+    B, C, H, W = x.shape
+    Co, _, KH, KW = w.shape
+    stride, padding = int(stride), int(padding)
+    if H + 2 * padding < KH or W + 2 * padding < KW or stride < 1 or padding < 0:
+        raise RuntimeError("kernel larger than the padded input, or bad stride / padding")
+    Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    bias = _f32_vec(bias, Co, "bias", x.device)
+    alpha = _f32_vec(alpha, Co, "alpha", x.device)
+    if out is None:
+        out = torch.empty((B, Co, Ho, Wo), dtype=out_dtype, device=x.device)
+    else:
+        require_device(out, "out")
+        if tuple(out.shape) != (B, Co, Ho, Wo) or out.dtype != out_dtype:
+            raise RuntimeError("out has the wrong shape or dtype")
+    L = lib()
+    code = _FLOAT_CODES[x.dtype]
+    need = L.miq_conv2d_w8_workspace(code, B, C, H, W, Co, KH, KW, stride, padding)
+    ws = torch.empty(need, dtype=torch.int8, device=x.device) if need else None
+    with _on(x.device):
+        _check(L.miq_conv2d_w8(_ptr(x), code, _ptr(w), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
+                               float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
     return out
 
 

@@ -45,6 +45,10 @@ struct W8fArgs {
     uint32_t plane_stride;
     int tiles_m, tiles_n;
     int kt_per_split;   // K-tiles per blockIdx.y slice; 0 = all of K
+    // Implicit-GEMM convolution (CONV kernels only): row m of X is output pixel m, whose K axis is KH runs of
+    // Lp elements (L = KW * Cp of them real) starting row_bytes apart in the padded channels-last planes.
+    int HoWo, Wo, cstride, Lp, L;
+    uint32_t row_bytes, pix_bytes, img_bytes, lp_magic;
 };
 
 __device__ __forceinline__ float bf16_round(float x) { return static_cast<float>(static_cast<__bf16>(x)); }
@@ -116,7 +120,7 @@ __device__ __forceinline__ float dequant1f(float acc, float bias, float alpha, f
 // STAGES = 2: double buffer, one __syncthreads per K-tile.  STAGES > 2: ring of K-tile buffers with
 // STAGES-1 tiles in flight behind a counted vmcnt and one raw barrier per K-tile (the thin problems,
 // whose K-tile of MFMAs is far shorter than a fetch).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES, bool CONV = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -137,8 +141,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
     const int m0 = tm * BM, n0 = tn * BN;
 
     const uint32_t kb = 2u * static_cast<uint32_t>(g.K);   // bytes per activation row
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, (NP - 1) * g.plane_stride + static_cast<uint32_t>(g.M) * kb);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.X, CONV ? NP * g.plane_stride : (NP - 1) * g.plane_stride + static_cast<uint32_t>(g.M) * kb);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * g.K);
+
+    // Convolution: byte offset of the window's first element for each tile row this lane stages.
+    constexpr int kRowsPerLane = CONV ? (BM / 8) / NWAVES : 1;
+    static_assert(!CONV || (BM / 8) % NWAVES == 0, "a lane must stage a fixed set of tile rows");
+    uint32_t pixbase[kRowsPerLane];
+    if constexpr (CONV) {
+#pragma unroll
+        for (int j = 0; j < kRowsPerLane; ++j) {
+            const int m = m0 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + j * NWAVES) * 8 + ((threadIdx.x & 63) >> 3);
+            if (m < g.M) {
+                const int b = m / g.HoWo, pix = m - b * g.HoWo, ho = pix / g.Wo, wo = pix - ho * g.Wo;
+                pixbase[j] = static_cast<uint32_t>(b) * g.img_bytes + static_cast<uint32_t>(ho * g.cstride) * g.row_bytes +
+                             static_cast<uint32_t>(wo * g.cstride) * g.pix_bytes;
+            } else {
+                pixbase[j] = kOob;
+            }
+        }
+    }
 
     v4f acc[FM][FN];
 #pragma unroll
@@ -160,9 +182,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
             const int p = sub >> 1, h = sub & 1;
             const int r = pc * 8 + r_in;
             const int c = slot ^ ((r >> 1) & 7);
-            const uint32_t kbyte = static_cast<uint32_t>(2 * kt + h) * kTileK + c * kChunk;
-            const int row = m0 + r;
-            const uint32_t off = (row < g.M && kbyte < kb) ? p * g.plane_stride + static_cast<uint32_t>(row) * kb + kbyte : kOob;
+            uint32_t off;
+            if constexpr (CONV) {
+                const uint32_t e0 = static_cast<uint32_t>(kt) * kTileK + 64 * h + 8 * c;   // first of this chunk's 8 elements
+                const uint32_t kh = __umulhi(e0, g.lp_magic), inrow = e0 - kh * g.Lp;
+                const uint32_t base = pixbase[i % kRowsPerLane];
+                off = (base != kOob && e0 < static_cast<uint32_t>(g.K) && inrow < static_cast<uint32_t>(g.L))
+                          ? p * g.plane_stride + base + kh * g.row_bytes + inrow * 2u : kOob;
+            } else {
+                const uint32_t kbyte = static_cast<uint32_t>(2 * kt + h) * kTileK + c * kChunk;
+                const int row = m0 + r;
+                off = (row < g.M && kbyte < kb) ? p * g.plane_stride + static_cast<uint32_t>(row) * kb + kbyte : kOob;
+            }
             dma16(rx, buf + q * (8 * kTileK), off);
         }
 #pragma unroll
@@ -263,7 +294,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = OUT == kOutRaw ? a[e] : dequant1f(a[e], bi[e], al[e], g.beta);
-            if constexpr (OUT == kOutBF16) {
+            if constexpr (CONV) {   // NCHW: the 16 lanes of a group hold 16 consecutive pixels of a channel
+                const int b = m / g.HoWo, pix = m - b * g.HoWo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= g.N) continue;
+                    const size_t o = (static_cast<size_t>(b) * g.N + n + e) * g.HoWo + pix;
+                    if constexpr (OUT == kOutBF16) {
+                        static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y[e]);
+                    } else {
+                        static_cast<float*>(g.out)[o] = y[e];
+                    }
+                }
+            } else if constexpr (OUT == kOutBF16) {
                 uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
                 if (vec_ok && n + 3 < g.N) {
                     *reinterpret_cast<uint2*>(o) = pack4_bf16(y[0], y[1], y[2], y[3]);
@@ -660,6 +703,117 @@ int launch_any(const void* x, const W8fArgs& g, hipStream_t st) {
     return check_launch("gemm_w8f_any_kernel");
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight-only Conv2d on floating-point activations: the same kernel as an implicit GEMM.  A pre-pass turns the
+// NCHW activation into zero-padded channels-last bf16 planes xp[plane][b][hp][wp][Cp] (Cp = Cin rounded up to
+// 8, so that a 16-byte chunk never leaves a pixel's channels) and the OIHW weight into wp[Cout][KH][Lp] with
+// (kw, c) order inside a filter row and zero fill (Lp = KW * Cp rounded up to 16): the K axis of output pixel
+// (b, ho, wo) is then KH contiguous runs of the padded copy, one padded row apart.  Nothing like an im2col
+// buffer is materialised.
+// ---------------------------------------------------------------------------------------
+struct ConvW8Geom {
+    int64_t B, Cin, H, W, Cout, KH, KW, stride, pad;
+    int64_t Ho, Wo, Hp, Wp, Cp, L, Lp, K, M;
+    int64_t plane_bytes, wp_bytes;
+};
+
+bool make_conv_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                       int64_t pad, ConvW8Geom& g) {
+    g = ConvW8Geom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    g.Hp = H + 2 * pad;
+    g.Wp = W + 2 * pad;
+    if (g.Hp < KH || g.Wp < KW) return false;
+    g.Ho = (g.Hp - KH) / stride + 1;
+    g.Wo = (g.Wp - KW) / stride + 1;
+    g.Cp = round_up(Cin, 8);
+    g.L = KW * g.Cp;
+    g.Lp = round_up(g.L, 16);
+    g.K = KH * g.Lp;
+    g.M = B * g.Ho * g.Wo;
+    g.plane_bytes = round_up(B * g.Hp * g.Wp * g.Cp * 2, 256);
+    g.wp_bytes = round_up(Cout * g.K, 256);
+    return true;
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(_Float16 v) { return static_cast<float>(v); }
+__device__ __forceinline__ float to_f32(__bf16 v) { return static_cast<float>(v); }
+
+// One item = eight channels of one padded pixel (pixels fastest, so that a wave reads runs of one channel plane).
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
+                                                             int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
+                                                             uint32_t npix, uint32_t items) {
+    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += 256u * gridDim.x) {
+        const uint32_t cg = it / npix, ppix = it - cg * npix;
+        const uint32_t b = ppix / (Hp * Wp), rem = ppix - b * (Hp * Wp);
+        const int hp = rem / Wp, wp = rem - hp * Wp, h = hp - pad, w = wp - pad;
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cg * 8 + j;
+                f[j] = c < Cin ? to_f32(x[((static_cast<size_t>(b) * Cin + c) * H + h) * W + w]) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float fh[2], fl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = f[2 * j + e];
+                    fh[e] = bf16_round(v);
+                    if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))
+                        fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+                    fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
+                }
+                hi[j] = pack2_bf16(fh[0], fh[1]);
+                lo[j] = pack2_bf16(fl[0], fl[1]);
+            }
+        }
+        uint16_t* o = xp + static_cast<size_t>(ppix) * Cp + cg * 8;
+        *reinterpret_cast<uint4*>(o) = uint4{hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (NP == 2) *reinterpret_cast<uint4*>(o + plane_elems) = uint4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
+// OIHW int8 -> wp[Cout][KH][Lp], (kw, c) order inside a filter row, zero where padded.
+__global__ __launch_bounds__(256) void conv_w8_pack_w_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, uint32_t total,
+                                                             int Cin, int KH, int KW, int Cp, int L, int Lp) {
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += 256u * gridDim.x) {
+        const uint32_t row = idx / Lp, l = idx - row * Lp, n = row / KH, kh = row - n * KH;
+        int8_t v = 0;
+        if (l < static_cast<uint32_t>(L)) {
+            const uint32_t kw = l / Cp, c = l - kw * Cp;
+            if (c < static_cast<uint32_t>(Cin)) v = w[((static_cast<size_t>(n) * Cin + c) * KH + kh) * KW + kw];
+        }
+        wp[idx] = v;
+    }
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT>
+int launch_conv_w8f(W8fArgs g, hipStream_t st) {
+    constexpr int BM = 128;
+    constexpr int STAGES = w8f_stages(BM, BN, NP);
+    g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
+    g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
+    constexpr int kLds = STAGES * (NP * 2 * BM + BN) * kTileK;
+    const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
+    if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_conv2d_w8: too many tiles");
+    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES, true>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
+    return check_launch("gemm_w8f_kernel (convolution)");
+}
+
+template <int NP, int OUT>
+int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
+    // 64-channel tiles up to 64 output channels (no empty tile columns), 128-channel tiles beyond
+    if (g.N <= 64) return launch_conv_w8f<64, 2, 2, NP, OUT>(g, st);
+    return launch_conv_w8f<128, 2, 4, NP, OUT>(g, st);
+}
+
 size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
     return x_dtype == MIQ_BF16 ? 0 : static_cast<size_t>(round_up(M * K * 2, 256));
 }
@@ -765,4 +919,70 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
         return run(tail, plan_w8f(M - m_main, N, K, planes));
     }
     return run(g, plan);
+}
+
+extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                                          int64_t KW, int64_t stride, int64_t pad) {
+    ConvW8Geom G;
+    if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
+    return static_cast<size_t>((x_dtype == MIQ_BF16 ? 1 : 2) * G.plane_bytes + G.wp_bytes);
+}
+
+extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    ConvW8Geom G;
+    MIQ_REQUIRE(make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G), MIQ_EINVAL,
+                "miq_conv2d_w8: bad geometry (B=%lld Cin=%lld H=%lld W=%lld Cout=%lld KH=%lld KW=%lld stride=%lld pad=%lld)",
+                (long long)B, (long long)Cin, (long long)H, (long long)W, (long long)Cout, (long long)KH, (long long)KW,
+                (long long)stride, (long long)pad);
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_conv2d_w8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_conv2d_w8: out_dtype must be MIQ_F32 or MIQ_BF16 (got %d)", out_dtype);
+    if (G.M == 0 || Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(x && w && out && alpha, MIQ_EINVAL, "miq_conv2d_w8: null pointer");
+    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
+                MIQ_ERANGE, "miq_conv2d_w8: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
+    const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2, esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(miq::aligned(x, xsz) && miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
+                "miq_conv2d_w8: x/out/alpha/bias not aligned to their element size");
+    const size_t need = miq_conv2d_w8_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, stride, pad);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE, "miq_conv2d_w8: needs %zu bytes of workspace (got %zu)",
+                need, workspace_bytes);
+    MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_w8: workspace must be 256-byte aligned");
+    hipStream_t st = miq::as_stream(stream);
+
+    uint16_t* xp = static_cast<uint16_t*>(workspace);
+    int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
+    const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp), items = npix * static_cast<uint32_t>(G.Cp / 8);
+    const int pgrid = static_cast<int>(items / 256 + 1 < 16384 ? items / 256 + 1 : 16384);
+    const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
+#define MIQ_PREP(T, NP)                                                                                              \
+    conv_w8_prep_x_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, (int)W, \
+                                                        (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, items)
+    if (x_dtype == MIQ_F32)
+        MIQ_PREP(float, 2);
+    else if (x_dtype == MIQ_F16)
+        MIQ_PREP(_Float16, 2);
+    else
+        MIQ_PREP(__bf16, 1);
+#undef MIQ_PREP
+    if (int rc = check_launch("conv_w8_prep_x_kernel")) return rc;
+    const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
+    conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
+        w, wp, wtotal, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L, (int)G.Lp);
+    if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
+
+    W8fArgs g{xp, wp, bias, alpha, out, beta, static_cast<int>(G.M), static_cast<int>(Cout), static_cast<int>(G.K),
+              static_cast<uint32_t>(G.plane_bytes), 0, 0, 0,
+              static_cast<int>(G.Ho * G.Wo), static_cast<int>(G.Wo), static_cast<int>(stride), static_cast<int>(G.Lp),
+              static_cast<int>(G.L), static_cast<uint32_t>(G.Wp * G.Cp * 2), static_cast<uint32_t>(G.Cp * 2),
+              static_cast<uint32_t>(G.Hp * G.Wp * G.Cp * 2),
+              static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Lp)) + 1u};
+    if (planes == 2) return out_dtype == MIQ_F32 ? launch_conv_w8f_np<2, kOutF32>(g, st) : launch_conv_w8f_np<2, kOutBF16>(g, st);
+    return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
 }

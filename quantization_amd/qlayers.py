@@ -29,6 +29,11 @@ def _single(v):
     return int(v)
 
 
+def _uniform(v):
+    """True for an integer or a tuple whose entries are all equal."""
+    return not isinstance(v, (tuple, list)) or len(set(v)) == 1
+
+
 class _QuantizerBase(nn.Module):
     def _init_common(self, in_features, out_features, kernel_size, stride, padding, dilation, groups, cnn,
                      data_metrics):
@@ -111,8 +116,14 @@ class _QuantizerBase(nn.Module):
                 x = x.to(torch.float32)
             out = _native.gemm_w8(x.reshape(-1, x.shape[-1]).contiguous(), w, bias=bias, alpha=alpha, beta=beta)
             return out.view(*lead, out.shape[-1])
-        # Conv2d on float activations: a library float convolution on a cached float copy of the weight,
-        # then the fused bias / scale epilogue.
+        # Conv2d: the same product as an implicit GEMM (miq_conv2d_w8) for what that kernel covers ...
+        if (not isinstance(self.padding, str) and _uniform(self.dilation) and _single(self.dilation) == 1
+                and self.groups == 1 and _uniform(self.stride) and _uniform(self.padding) and x.dim() == 4):
+            if x.dtype == torch.float64:
+                x = x.to(torch.float32)
+            return _native.conv2d_w8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha, beta=beta)
+        # ... and otherwise (dilation, groups, unequal strides, string padding) a library float convolution on a
+        # cached float copy of the weight, then the fused bias / scale epilogue.
         if self._wfloat is None or self._wfloat.dtype != x.dtype or self._wfloat.device != w.device \
                 or self._wfloat_src is not self.weight:
             self._wfloat, self._wfloat_src = w.to(x.dtype), self.weight

@@ -1,0 +1,105 @@
+"""Weight-only Conv2d on floating-point activations (miq_conv2d_w8, through the C ABI and the drop-in layer) against
+an fp64 convolution and the reference's own outputs.
+
+Bar as for the Linear (tests/test_gpu_w8f.py): the reference convolves in the activation's precision
+(`F.conv2d(x, weight.to(x.dtype), ...)`, quant/Weight_Only/Quantizer.py:72-91) and outputs must agree within 1e-3
+relative; the kernel is held to 5e-5 of the sum of magnitudes per element.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import Golden
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+FW = Golden("wo_forward.npz")
+Q_PARAMS = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+
+
+@pytest.fixture(scope="module")
+def N():
+    from quantization_amd import _native
+    _native.lib()
+    return _native
+
+
+def check(N, B, C, H, W, Co, k, s, p, xdt, seed, bias=True, out_dtype=torch.float32, beta=0.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g).to(DT[xdt])
+    w = torch.randint(-128, 128, (Co, C, k, k), generator=g, dtype=torch.int32).to(torch.int8)
+    alpha = torch.rand(Co, generator=g) * 0.02 + 1e-4
+    b = torch.randn(Co, generator=g) * 5 if bias else None
+    y = N.conv2d_w8(x.cuda(), w.cuda(), s, p, bias=None if b is None else b.cuda(), alpha=alpha.cuda(), beta=beta,
+                    out_dtype=out_dtype)
+    torch.cuda.synchronize()
+    xd, wd = x.double(), w.double()
+    bd = torch.zeros(Co, dtype=torch.float64) if b is None else b.double()
+    a4 = alpha.double().view(1, -1, 1, 1)
+    ref = (F.conv2d(xd, wd, stride=s, padding=p) + bd.view(1, -1, 1, 1)) * a4 + beta
+    mag = (F.conv2d(xd.abs(), wd.abs(), stride=s, padding=p) + bd.abs().view(1, -1, 1, 1)) * a4 + abs(beta)
+    assert tuple(y.shape) == tuple(ref.shape) and y.dtype == out_dtype
+    err = (y.cpu().double() - ref).abs()
+    tol = 5e-5 * mag + 1e-30
+    if out_dtype == torch.bfloat16:
+        tol = tol + ref.abs() * 2.0 ** -8
+    worst = float((err / tol).max())
+    assert worst <= 1.0, f"worst error / tolerance = {worst:.3f}"
+
+
+CASES = [
+    (2, 3, 8, 8, 5, 3, 1, 1), (2, 8, 9, 11, 16, 3, 2, 1), (1, 4, 5, 5, 6, 1, 1, 0), (3, 3, 32, 32, 64, 3, 1, 1),
+    (2, 64, 14, 14, 128, 3, 1, 1), (2, 3, 30, 30, 64, 7, 2, 3), (4, 16, 12, 12, 130, 1, 2, 0), (1, 70, 9, 9, 33, 3, 1, 0),
+    (2, 32, 16, 16, 64, 3, 2, 1), (5, 24, 7, 7, 200, 5, 1, 2), (1, 1, 4, 4, 1, 2, 1, 0), (2, 128, 7, 7, 256, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", CASES)
+def test_conv_w8_shapes(N, B, C, H, W, Co, k, s, p, xdt):
+    check(N, B, C, H, W, Co, k, s, p, xdt, seed=B * 100 + C + Co)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "bf16"])
+def test_conv_w8_bf16_out_no_bias(N, xdt):
+    check(N, 2, 16, 10, 10, 72, 3, 1, 1, xdt, seed=3, bias=False, out_dtype=torch.bfloat16, beta=0.5)
+
+
+def test_conv_w8_resnet_layer(N):
+    check(N, 32, 64, 56, 56, 64, 3, 1, 1, "f32", seed=9)
+    check(N, 32, 128, 28, 28, 128, 3, 1, 1, "bf16", seed=10)
+
+
+@pytest.mark.parametrize("case", [c for c in FW.cases() if c.startswith("conv")])
+def test_conv_w8_golden_layer_forward(N, case):
+    """The reference's Quantizer.forward outputs for Conv2d layers (integer-valued float activations: every product
+    and sum is exact, so the drop-in layer must reproduce them to the last bit of the epilogue)."""
+    from quantization_amd.quant.Weight_Only import Quantizer
+    w, x, ref = FW.get(case, "w"), FW.get(case, "x"), FW.get(case, "y")
+    bias = FW.get(case, "bias")
+    stride, pad = (int(v) for v in FW.get(case, "stride_pad"))
+    conv = torch.nn.Conv2d(w.shape[1], w.shape[0], w.shape[2], stride=stride, padding=pad, bias=bias is not None)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+        if bias is not None:
+            conv.bias.copy_(torch.from_numpy(bias))
+    ql = Quantizer.from_float(module=conv, data_metry=Q_PARAMS, quantize_output=False)
+    y = ql(torch.from_numpy(x).float().cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_conv_w8_argument_checks(N):
+    x = torch.randn(1, 4, 6, 6).cuda()
+    w = torch.zeros(8, 4, 3, 3, dtype=torch.int8).cuda()
+    a = torch.ones(8).cuda()
+    with pytest.raises(RuntimeError):
+        N.conv2d_w8(x.cpu(), w, alpha=a)
+    with pytest.raises(RuntimeError):
+        N.conv2d_w8(x, w[:, :2].contiguous(), alpha=a)
+    with pytest.raises(RuntimeError):
+        N.conv2d_w8(x, w, alpha=None)
+    with pytest.raises(RuntimeError):
+        N.conv2d_w8(x[:, :, :2, :2].contiguous(), w, alpha=a)
+    assert N.conv2d_w8(x, w, 1, 1, alpha=a).shape == (1, 8, 6, 6)
