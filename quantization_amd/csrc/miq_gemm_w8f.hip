@@ -740,9 +740,60 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(_Float16 v) { return static_cast<float>(v); }
 __device__ __forceinline__ float to_f32(__bf16 v) { return static_cast<float>(v); }
 
-// One item = eight channels of one padded pixel (pixels fastest, so that a wave reads runs of one channel plane).
+// A workgroup moves 64 consecutive padded pixels (flat over b, hp, wp) x 64 channels through an LDS tile: reads run
+// along the pixels of one channel plane (256-byte runs), writes along the channels of one pixel (eight lanes fill a
+// pixel's 128 bytes per plane).  Border pixels and channels past Cin are written as zeros.
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
+                                                             int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
+                                                             uint32_t npix, int cblocks) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const uint32_t pix0 = (blockIdx.x / cblocks) * 64u;
+    const int c0 = (blockIdx.x % cblocks) * 64;
+    {
+        const uint32_t pp = pix0 + (t & 63);
+        const uint32_t b = pp / (Hp * Wp), rem = pp - b * (Hp * Wp);
+        const int hp = rem / Wp, wp = rem - hp * Wp, h = hp - pad, w = wp - pad;
+        const bool inside = pp < npix && h >= 0 && h < H && w >= 0 && w < W;
+        const size_t src = (static_cast<size_t>(b) * Cin * H + h) * W + w;   // channel 0 of this pixel
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cl = (t >> 6) + 4 * i, c = c0 + cl;
+            tile[cl][t & 63] = (inside && c < Cin) ? to_f32(x[src + static_cast<size_t>(c) * H * W]) : 0.0f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int it = t + 256 * k, pixl = it >> 3, cg = it & 7;
+        const uint32_t pp = pix0 + pixl;
+        if (pp >= npix || c0 + cg * 8 >= Cp) continue;
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float fh[2], fl[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float v = tile[cg * 8 + 2 * j + e][pixl];
+                fh[e] = bf16_round(v);
+                if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))
+                    fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+                fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
+            }
+            hi[j] = pack2_bf16(fh[0], fh[1]);
+            lo[j] = pack2_bf16(fl[0], fl[1]);
+        }
+        uint16_t* o = xp + static_cast<size_t>(pp) * Cp + c0 + cg * 8;
+        *reinterpret_cast<uint4*>(o) = uint4{hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (NP == 2) *reinterpret_cast<uint4*>(o + plane_elems) = uint4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
+// Few channels (Cp <= 16: first layers): one item = eight channels of one padded pixel, pixels fastest, so that a
+// wave reads runs of one channel plane; no LDS.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void conv_w8_prep_x_small_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
                                                              uint32_t npix, uint32_t items) {
     for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += 256u * gridDim.x) {
@@ -958,12 +1009,23 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
 
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
-    const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp), items = npix * static_cast<uint32_t>(G.Cp / 8);
-    const int pgrid = static_cast<int>(items / 256 + 1 < 16384 ? items / 256 + 1 : 16384);
+    const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp);
+    const int cblocks = static_cast<int>(ceil_div(G.Cp, 64));
+    const int64_t pblocks = ceil_div(npix, 64) * cblocks;
+    MIQ_REQUIRE(pblocks < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8: too many re-layout blocks");
+    const int pgrid = static_cast<int>(pblocks);
+    const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
+    const int sgrid = static_cast<int>(sitems / 256 + 1 < 16384 ? sitems / 256 + 1 : 16384);
     const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
 #define MIQ_PREP(T, NP)                                                                                              \
-    conv_w8_prep_x_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, (int)W, \
-                                                        (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, items)
+    do {                                                                                                             \
+        if (G.Cp <= 16)                                                                                              \
+            conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems); \
+        else                                                                                                         \
+            conv_w8_prep_x_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, (int)W, \
+                                                                (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, cblocks); \
+    } while (0)
     if (x_dtype == MIQ_F32)
         MIQ_PREP(float, 2);
     else if (x_dtype == MIQ_F16)
