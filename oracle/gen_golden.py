@@ -256,6 +256,10 @@ def wo_forward_float_cases(mods):
         "f32_lin_48_200_wide": (torch.nn.Linear(48, 200), (65, 48), torch.float32, 50.0),
         "f32_lin_2048_32": (torch.nn.Linear(2048, 32), (2, 2048), torch.float32, 0.1),
         "bf16_lin_256_72": (torch.nn.Linear(256, 72), (19, 256), torch.bfloat16, 1.0),
+        "f32_conv_3_5_p1": (torch.nn.Conv2d(3, 5, 3, padding=1), (2, 3, 8, 8), torch.float32, 1.0),
+        "f32_conv_8_16_s2": (torch.nn.Conv2d(8, 16, 3, stride=2, padding=1), (2, 8, 9, 11), torch.float32, 3.0),
+        "f32_conv_20_40_1x1_nobias": (torch.nn.Conv2d(20, 40, 1, bias=False), (3, 20, 5, 5), torch.float32, 1.0),
+        "f32_conv_16_24_5x5": (torch.nn.Conv2d(16, 24, 5, padding=2), (2, 16, 12, 12), torch.float32, 0.2),
     }
     for name, (mod, xshape, dt, mag) in cases.items():
         ql = Quantizer.from_float(module=mod, data_metry=Q_PARAMS, quantize_output=False)
@@ -270,6 +274,8 @@ def wo_forward_float_cases(mods):
         out[name + "/q"] = ql.weight.numpy()
         out[name + "/scales"] = as_f32(ql.weight_quant.scales).reshape(-1)
         out[name + "/y"] = as_f32(y)
+        if isinstance(mod, torch.nn.Conv2d):
+            out[name + "/stride_pad"] = np.array([mod.stride[0], mod.padding[0]], dtype=np.int64)
     return out
 
 

@@ -218,6 +218,25 @@ def wo_conv2d_forward(x_i8, wq, scale, bias=None, stride=1, padding=0):
     return epilogue(acc, bias, np.asarray(scale).reshape(-1), 0.0, channel_axis=1)
 
 
+def wo_conv2d_forward_float(x, wq, scale, bias=None, stride=1, padding=0):
+    """Weight-only Quantizer.forward for a Conv2d layer on real-valued activations
+    (quant/Weight_Only/Quantizer.py:72-91: F.conv2d(x, weight.to(x.dtype), stride, padding), `+ bias`, dequantize).
+    Summed in float64 and rounded once, as wo_linear_forward_float."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(wq, dtype=np.float64)
+    B, C, H, W = x.shape
+    Co, _, KH, KW = w.shape
+    xp = np.zeros((B, C, H + 2 * padding, W + 2 * padding), dtype=np.float64)
+    xp[:, :, padding:padding + H, padding:padding + W] = x
+    Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    acc = np.zeros((B, Co, Ho, Wo), dtype=np.float64)
+    for i in range(KH):
+        for j in range(KW):
+            patch = xp[:, :, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride]
+            acc += np.einsum("bchw,oc->bohw", patch, w[:, :, i, j])
+    return epilogue(acc.astype(np.float32), bias, np.asarray(scale).reshape(-1), 0.0, channel_axis=1)
+
+
 def dequantize(q, scales, zero_point):
     """Qop.dequantize (quant/Weight_Only/Qop.py:179): scales * (float(q) - zero_point)."""
     return (np.asarray(scales, dtype=np.float32) *

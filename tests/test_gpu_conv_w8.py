@@ -90,6 +90,24 @@ def test_conv_w8_golden_layer_forward(N, case):
     np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6)
 
 
+FF = Golden("wo_forward_float.npz")
+
+
+@pytest.mark.parametrize("case", [c for c in FF.cases() if "conv" in c])
+def test_conv_w8_golden_real_valued_activations(N, case):
+    """The reference's own Quantizer.forward outputs for Conv2d on real-valued fp32 activations (fixture made by
+    oracle/gen_golden.py wo_float): within 1e-3 of the reference, 5e-5 of the sum of magnitudes of the oracle."""
+    from oracle import oracle_np as O
+    x, q, s, ref = FF.get(case, "x"), FF.get(case, "q"), FF.get(case, "scales"), FF.get(case, "y")
+    bias = FF.get(case, "bias")
+    stride, pad = (int(v) for v in FF.get(case, "stride_pad"))
+    y = N.conv2d_w8(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), stride, pad,
+                    bias=None if bias is None else torch.from_numpy(bias).cuda(), alpha=torch.from_numpy(s).cuda()).cpu().numpy()
+    mag = O.wo_conv2d_forward_float(np.abs(x), np.abs(q.astype(np.int16)), s, None if bias is None else np.abs(bias), stride, pad)
+    np.testing.assert_array_less(np.abs(y - O.wo_conv2d_forward_float(x, q, s, bias, stride, pad)), 5e-5 * mag + 1e-30)
+    np.testing.assert_array_less(np.abs(y - ref), 1e-3 * np.maximum(np.abs(ref), 1e-2 * mag) + 1e-30)
+
+
 def test_conv_w8_argument_checks(N):
     x = torch.randn(1, 4, 6, 6).cuda()
     w = torch.zeros(8, 4, 3, 3, dtype=torch.int8).cuda()

@@ -63,7 +63,7 @@ def check(N, x, w, b, alpha, beta=0.0, out_dtype=torch.float32):
     return y
 
 
-@pytest.mark.parametrize("case", FF.cases())
+@pytest.mark.parametrize("case", [c for c in FF.cases() if "conv" not in c])
 def test_w8f_golden_reference_outputs(N, case):
     """The reference's own Quantizer.forward outputs on real-valued activations (fixture made by
     oracle/gen_golden.py from the reference's Python), through the C ABI and through the drop-in layer."""
@@ -73,7 +73,7 @@ def test_w8f_golden_reference_outputs(N, case):
     xt = torch.from_numpy(x).to(xdt)
     y = N.gemm_w8(xt.cuda(), torch.from_numpy(q).cuda(), bias=None if bias is None else torch.from_numpy(bias).cuda(),
                   alpha=torch.from_numpy(s).cuda()).cpu().numpy()
-    mag = (np.abs(x).astype(np.float64) @ np.abs(q).astype(np.float64).T + (0 if bias is None else np.abs(bias))) * s
+    mag = (np.abs(x).astype(np.float64) @ np.abs(q.astype(np.float64)).T + (0 if bias is None else np.abs(bias))) * s
     # against the oracle: 5e-5 of the sum of magnitudes; against the reference: 1e-3 (bf16 activations: the
     # reference rounds its product to bf16, so bf16 resolution)
     np.testing.assert_array_less(np.abs(y - O.wo_linear_forward_float(x, q, s, bias)), 5e-5 * mag + 1e-30)

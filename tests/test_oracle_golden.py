@@ -69,9 +69,14 @@ def test_wo_forward_float_matches_reference(case):
     q2, s2, _ = O.quantize_channel_sym_int8(FF.get(case, "w"))
     np.testing.assert_array_equal(q2, q)
     np.testing.assert_array_equal(s2.reshape(-1), s)
-    y = O.wo_linear_forward_float(x, q, s, bias)
     ref = FF.get(case, "y")
-    mag = (np.abs(x).astype(np.float64) @ np.abs(q).astype(np.float64).T + (0 if bias is None else np.abs(bias))) * s
+    if "conv" in case:
+        stride, pad = (int(v) for v in FF.get(case, "stride_pad"))
+        y = O.wo_conv2d_forward_float(x, q, s, bias, stride, pad)
+        mag = O.wo_conv2d_forward_float(np.abs(x), np.abs(q.astype(np.int16)), s, None if bias is None else np.abs(bias), stride, pad)
+    else:
+        y = O.wo_linear_forward_float(x, q, s, bias)
+        mag = (np.abs(x).astype(np.float64) @ np.abs(q.astype(np.float64)).T + (0 if bias is None else np.abs(bias))) * s
     rel = 2.0 ** -6 if case.startswith("bf16") else 1e-5
     assert np.all(np.abs(y - ref) <= rel * mag + 1e-30), float(np.max(np.abs(y - ref) / mag))
 
