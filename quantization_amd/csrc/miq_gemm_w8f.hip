@@ -843,10 +843,9 @@ __global__ __launch_bounds__(256) void conv_w8_pack_w_kernel(const int8_t* __res
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT>
+template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int DEPTH = 0, int BM = 128>
 int launch_conv_w8f(W8fArgs g, hipStream_t st) {
-    constexpr int BM = 128;
-    constexpr int STAGES = w8f_stages(BM, BN, NP);
+    constexpr int STAGES = DEPTH ? DEPTH : w8f_stages(BM, BN, NP);
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.N, BN));
     constexpr int kLds = STAGES * (NP * 2 * BM + BN) * kTileK;
@@ -861,7 +860,24 @@ int launch_conv_w8f(W8fArgs g, hipStream_t st) {
 template <int NP, int OUT>
 int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
     // 64-channel tiles up to 64 output channels (no empty tile columns), 128-channel tiles beyond
-    if (g.N <= 64) return launch_conv_w8f<64, 2, 2, NP, OUT>(g, st);
+    const char* d = dev_switch("MIQ_CONV_W8_TILE");   // developer A/B switch
+    if (d) {
+        switch (d[0]) {
+            case 'a': return launch_conv_w8f<64, 2, 2, NP, OUT, 2>(g, st);            // 128 x 64, double-buffered
+            case 'b': return launch_conv_w8f<128, 2, 4, NP, OUT, 2>(g, st);           // 128 x 128, double-buffered
+            case 'c': return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 64>(g, st);        // 64 x 64, double-buffered
+            case 'd': return launch_conv_w8f<128, 2, 2, NP, OUT, 2, 64>(g, st);       // 64 x 128, double-buffered
+            case 'e': return launch_conv_w8f<64, 2, 2, NP, OUT, 0, 64>(g, st);        // 64 x 64, deepest ring
+            default: break;
+        }
+    }
+    // Up to 64 output channels (the large-image layers, K of a few hundred): two double-buffered workgroups per CU
+    // (80 KiB of LDS each) hide each other's fetches better than one with a deeper ring: 128 x 64 tiles for one plane
+    // (239 against 354 us on 64->64 56x56 at batch 256), 64 x 64 for two (361 against 478 us).
+    if (g.N <= 64) {
+        if constexpr (NP == 1) return launch_conv_w8f<64, 2, 2, NP, OUT, 2>(g, st);
+        return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 64>(g, st);
+    }
     return launch_conv_w8f<128, 2, 4, NP, OUT>(g, st);
 }
 
