@@ -69,6 +69,24 @@ def config3():
               f"{total_ops / total_us / 1e6:.0f} TOPS, {B / total_us * 1e6:.0f} images/s through the convolutions", flush=True)
 
 
+    # the same stack as the reference's weight-only layers run it: floating-point activations (miq_conv2d_w8), beside
+    # the library route (float convolution on a float copy of the weight + the fused epilogue kernel)
+    import torch.nn.functional as F
+    for dt in (torch.float32, torch.bfloat16):
+        ours_us, lib_us = 0.0, 0.0
+        for C, H, Co, k, s, p, times in layers:
+            x = torch.randn(B, C, H, H, device="cuda").to(dt)
+            w = rand_i8((Co, C, k, k))
+            wf = w.to(dt)
+            alpha = torch.rand(Co, device="cuda") * 0.01
+            ours_us += times * med_us(lambda: N.conv2d_w8(x, w, s, p, alpha=alpha), iters=7)
+            lib_us += times * med_us(lambda: N.epilogue_channels_f32(F.conv2d(x, wf, stride=s, padding=p).float().contiguous(),
+                                                                      None, alpha, 0.0), iters=7)
+            del x, w, wf
+        print(f"config 3, weight-only, {str(dt)[6:]} activations, fp32 out: {ours_us:.0f} us in all ({B / ours_us * 1e6:.0f} images/s); "
+              f"library convolution + epilogue {lib_us:.0f} us ({lib_us / ours_us:.2f}x)", flush=True)
+
+
 def config4():
     torch.manual_seed(0)
     shapes = {"gate": (14336, 4096), "up": (14336, 4096), "down": (4096, 14336)}
