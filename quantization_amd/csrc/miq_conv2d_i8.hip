@@ -34,6 +34,10 @@ struct ConvGeom {
     bool planar;
     int64_t pitch;   // pixels per padded row (Wp rounded up to 4)
     int64_t ptot;    // flat padded pixels B * Hp * pitch
+    // 1 x 1 filters with a stride and no padding read only every stride-th pixel of every stride-th row: the
+    // re-layout keeps just those (sub = the caller's stride, Hs x Ws = the caller's image) and the problem
+    // continues as a stride-1 convolution over an Ho x Wo image (H, W, stride above are then the reduced ones).
+    int64_t sub, Hs, Ws;
 };
 
 // conv3x3_planar_kernel's tile: kTM output pixels of one image x 64 output channels per workgroup; one stage =
@@ -46,8 +50,15 @@ constexpr int kPlanarStage = kPatchBytes + kWStageBytes;
 
 bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                int64_t pad, ConvGeom& g) {
-    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0};
+    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
+    if (KH == 1 && KW == 1 && pad == 0 && stride > 1 && H * W < (1ll << 30) && !(ss && ss[0] == '0')) {
+        g.sub = stride;
+        g.H = H = (H - 1) / stride + 1;
+        g.W = W = (W - 1) / stride + 1;
+        g.stride = stride = 1;
+    }
     g.Hp = H + 2 * pad;
     g.Wp = W + 2 * pad;
     if (g.Hp < KH || g.Wp < KW) return false;
@@ -136,10 +147,16 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint3
 //
 // plane_stride != 0 selects the chunk-plane layout instead: xp[c / 16][b][hp][wp][c % 16], planes
 // plane_stride bytes apart, Wp then being the row pitch in pixels (Cp is a multiple of 64 there).
-template <bool DWORD>
+//
+// sub > 1 (1 x 1 filters with a stride): the H x W image re-laid is every sub-th pixel of every sub-th row of
+// a source image Ws pixels wide whose channel planes are HWs pixels apart.  MODE 0 gathers single bytes, MODE 1
+// dwords (sub == 1), MODE 2 serves sub == 2 with W % 4 == 0 and Ws % 4 == 0: the four pixels of a thread are
+// the even bytes of one aligned 8-byte run of the source row.
+template <int MODE>
 __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin, int H,
                                                     int W, int Hp, int Wp, int Cp, int pad, int cblocks, int bx,
-                                                    int64_t b, int64_t plane_stride = 0) {
+                                                    int64_t b, int64_t plane_stride = 0, int sub = 1, int Ws = 0,
+                                                    int HWs = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 16];
     const int t = threadIdx.x;
     const int HW = H * W;
@@ -148,18 +165,38 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
     {
         const int p4 = t & 15, cg = t >> 4;
         uint32_t r[4], d[4];
+        const int pf = p0 + p4 * 4;   // first of this thread's four pixels
+        int so[4] = {0, 0, 0, 0};     // sub > 1: their offsets inside a source channel plane
+        if (MODE != 1 && sub > 1) {
+#pragma unroll
+            for (int k = 0; k < (MODE == 2 ? 1 : 4); ++k) {
+                const int h = (pf + k) / W, w = pf + k - h * W;
+                so[k] = h * sub * Ws + w * sub;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + cg * 4 + j;
-            const int8_t* src = x + (b * Cin + c) * HW + p0 + p4 * 4;
             r[j] = 0u;
             if (c < Cin) {
-                if constexpr (DWORD) {
-                    if (p0 + p4 * 4 < HW) r[j] = *reinterpret_cast<const uint32_t*>(src);
-                } else {
+                if constexpr (MODE == 1) {
+                    const int8_t* src = x + (b * Cin + c) * HW + pf;
+                    if (pf < HW) r[j] = *reinterpret_cast<const uint32_t*>(src);
+                } else if constexpr (MODE == 2) {
+                    if (pf < HW) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(x + (b * Cin + c) * HWs + so[0]);
+                        r[j] = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);   // bytes 0, 2 of v.x, then of v.y
+                    }
+                } else if (sub > 1) {
+                    const int8_t* src = x + (b * Cin + c) * HWs;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (p0 + p4 * 4 + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                        if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[so[k]])) << (8 * k);
+                } else {
+                    const int8_t* src = x + (b * Cin + c) * HW + pf;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
                 }
             }
         }
@@ -311,13 +348,14 @@ struct ConvPrepArgs {
     uint32_t border_total, weight_total;   // border pixels of all images; dwords of packed weights
     int64_t plane_stride;   // != 0: chunk-plane layout (Wp = row pitch), weights packed for conv3x3_planar_kernel
     int Cout;
+    int sub, Ws, HWs;       // sub > 1: keep every sub-th pixel of every sub-th row of a Ws-wide source image
 };
 
-template <bool DWORD>
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
     if (static_cast<int>(blockIdx.x) < a.n_interior) {
-        nhwc_interior_block<DWORD>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y,
-                                   a.plane_stride);
+        nhwc_interior_block<MODE>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y,
+                                  a.plane_stride, a.sub, a.Ws, a.HWs);
         return;
     }
     const uint32_t first = (blockIdx.y * a.n_extra + (blockIdx.x - a.n_interior)) * 256u + threadIdx.x;
@@ -920,6 +958,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
                 "miq_conv2d_i8: needs %zu bytes of workspace (got %zu)", need, workspace_bytes);
     MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_i8: workspace must be 256-byte aligned");
     hipStream_t st = miq::as_stream(stream);
+    H = G.H; W = G.W; stride = G.stride;   // a subsampled 1 x 1 layer continues as its stride-1 equivalent
 
     int8_t* xp = static_cast<int8_t*>(workspace);
     int8_t* wp = xp + miq::round_up(G.xp_bytes, 256);
@@ -942,11 +981,11 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if ((H * W) % 4 == 0 && miq::aligned(x, 4))
-                conv_prep_kernel<true><<<pgrid, 256, 0, st>>>(pa);
+                conv_prep_kernel<1><<<pgrid, 256, 0, st>>>(pa);
             else
-                conv_prep_kernel<false><<<pgrid, 256, 0, st>>>(pa);
+                conv_prep_kernel<0><<<pgrid, 256, 0, st>>>(pa);
             packed = true;
-        } else if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4) {
+        } else if (W % 4 == 0 && miq::aligned(x, 4) && G.Cp == 4 && G.sub == 1) {
             const int64_t total4 = B * G.Hp * (W / 4);
             const int g4 = static_cast<int>(total4 / 256 + 1 < (1 << 20) ? total4 / 256 + 1 : (1 << 20));
             nhwc_pad_c4_kernel<<<g4, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)pad, total4);
@@ -959,16 +998,20 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
             pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+            pa.sub = (int)G.sub; pa.Ws = (int)G.Ws; pa.HWs = (int)(G.Hs * G.Ws);
             // about four border pixels / weight dwords per extra thread, spread over the images' grid rows
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
-            if ((H * W) % 4 == 0 && miq::aligned(x, 4))
-                conv_prep_kernel<true><<<pgrid, 256, 0, st>>>(pa);
+            if (G.sub == 2 && W % 4 == 0 && G.Ws % 4 == 0 && (G.Hs * G.Ws) % 8 == 0 && miq::aligned(x, 8))
+                conv_prep_kernel<2><<<pgrid, 256, 0, st>>>(pa);
+            else if (G.sub == 1 && (H * W) % 4 == 0 && miq::aligned(x, 4))
+                conv_prep_kernel<1><<<pgrid, 256, 0, st>>>(pa);
             else
-                conv_prep_kernel<false><<<pgrid, 256, 0, st>>>(pa);
+                conv_prep_kernel<0><<<pgrid, 256, 0, st>>>(pa);
             packed = true;
         } else {
+            MIQ_REQUIRE(G.sub == 1, MIQ_ERANGE, "miq_conv2d_i8: image too large for the subsampling re-layout");
             nhwc_pad_kernel<<<grid, 256, 0, st>>>(x, xp, (int)Cin, (int)H, (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp,
                                                   (int)pad, cblocks);
         }

@@ -269,6 +269,10 @@ CONV_SHAPES = [
     (3, 128, 28, 28, 70, 3, 1, 1), (5, 64, 20, 20, 64, 3, 1, 1), (5, 64, 22, 22, 32, 3, 1, 0),
     (2, 192, 42, 42, 70, 3, 1, 1), (5, 64, 18, 18, 64, 3, 1, 2), (2, 64, 56, 56, 8, 3, 1, 1),
     (5, 64, 20, 21, 16, 3, 1, 1), (6, 64, 16, 16, 64, 3, 1, 1), (40, 64, 8, 8, 64, 3, 1, 1),
+    # 1 x 1 filters with a stride and no padding: the re-layout keeps only the pixels the filter visits (stride 2
+    # from aligned 8-byte runs; odd sizes, ragged channels, stride 3 and a 3-channel image by single bytes)
+    (2, 64, 16, 16, 128, 1, 2, 0), (3, 70, 24, 40, 20, 1, 2, 0), (2, 16, 15, 17, 8, 1, 2, 0),
+    (2, 32, 13, 13, 8, 1, 3, 0), (1, 3, 9, 9, 4, 1, 2, 0), (2, 8, 12, 20, 8, 1, 2, 0), (2, 128, 56, 56, 64, 1, 2, 0),
 ]
 
 
@@ -311,7 +315,9 @@ def test_conv_resnet_layer_vs_torch(N):
                                               (5, 32, 12, 12, 200, 3, 1, 1), (2, 4, 18, 18, 9, 3, 2, 0),
                                               # the LDS-resident-patch kernel
                                               (5, 64, 20, 20, 70, 3, 1, 1), (3, 128, 28, 28, 24, 3, 1, 1),
-                                              (5, 64, 20, 21, 16, 3, 1, 1)])
+                                              (5, 64, 20, 21, 16, 3, 1, 1),
+                                              # strided 1 x 1: the subsampling re-layout
+                                              (2, 64, 16, 16, 70, 1, 2, 0), (2, 24, 9, 11, 12, 1, 2, 0)])
 def test_conv_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p):
     x, w = rand_i8((B, C, H, W), 9), rand_i8((Co, C, k, k), 10)
     g = torch.Generator().manual_seed(4)
