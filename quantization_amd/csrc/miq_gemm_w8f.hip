@@ -715,12 +715,23 @@ struct ConvW8Geom {
     int64_t B, Cin, H, W, Cout, KH, KW, stride, pad;
     int64_t Ho, Wo, Hp, Wp, Cp, L, Lp, K, M;
     int64_t plane_bytes, wp_bytes;
+    // 1 x 1 filters with a stride and no padding visit only every stride-th pixel of every stride-th row: the
+    // re-layout keeps just those (sub = the caller's stride, Hs x Ws = the caller's image) and the problem
+    // continues as a stride-1 convolution over an Ho x Wo image (H, W, stride above are then the reduced ones).
+    int64_t sub, Hs, Ws;
 };
 
 bool make_conv_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                        int64_t pad, ConvW8Geom& g) {
-    g = ConvW8Geom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    g = ConvW8Geom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
+    if (KH == 1 && KW == 1 && pad == 0 && stride > 1 && !(ss && ss[0] == '0')) {
+        g.sub = stride;
+        g.H = H = (H - 1) / stride + 1;
+        g.W = W = (W - 1) / stride + 1;
+        g.stride = stride = 1;
+    }
     g.Hp = H + 2 * pad;
     g.Wp = W + 2 * pad;
     if (g.Hp < KH || g.Wp < KW) return false;
@@ -746,7 +757,7 @@ __device__ __forceinline__ float to_f32(__bf16 v) { return static_cast<float>(v)
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                             uint32_t npix, int cblocks) {
+                                                             uint32_t npix, int cblocks, int sub, int Hs, int Ws) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x;
     const uint32_t pix0 = (blockIdx.x / cblocks) * 64u;
@@ -756,11 +767,12 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
         const uint32_t b = pp / (Hp * Wp), rem = pp - b * (Hp * Wp);
         const int hp = rem / Wp, wp = rem - hp * Wp, h = hp - pad, w = wp - pad;
         const bool inside = pp < npix && h >= 0 && h < H && w >= 0 && w < W;
-        const size_t src = (static_cast<size_t>(b) * Cin * H + h) * W + w;   // channel 0 of this pixel
+        // channel 0 of this pixel in the Hs x Ws source image (every sub-th pixel of every sub-th row is kept)
+        const size_t src = (static_cast<size_t>(b) * Cin * Hs + h * sub) * Ws + w * sub;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cl = (t >> 6) + 4 * i, c = c0 + cl;
-            tile[cl][t & 63] = (inside && c < Cin) ? to_f32(x[src + static_cast<size_t>(c) * H * W]) : 0.0f;
+            tile[cl][t & 63] = (inside && c < Cin) ? to_f32(x[src + static_cast<size_t>(c) * Hs * Ws]) : 0.0f;
         }
     }
     __syncthreads();
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_small_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                             uint32_t npix, uint32_t items) {
+                                                             uint32_t npix, uint32_t items, int sub, int Hs, int Ws) {
     for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += 256u * gridDim.x) {
         const uint32_t cg = it / npix, ppix = it - cg * npix;
         const uint32_t b = ppix / (Hp * Wp), rem = ppix - b * (Hp * Wp);
@@ -806,7 +818,7 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_small_kernel(const T* __re
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = cg * 8 + j;
-                f[j] = c < Cin ? to_f32(x[((static_cast<size_t>(b) * Cin + c) * H + h) * W + w]) : 0.0f;
+                f[j] = c < Cin ? to_f32(x[((static_cast<size_t>(b) * Cin + c) * Hs + h * sub) * Ws + w * sub]) : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1022,6 +1034,7 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
                 need, workspace_bytes);
     MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_w8: workspace must be 256-byte aligned");
     hipStream_t st = miq::as_stream(stream);
+    H = G.H; W = G.W; stride = G.stride;   // a subsampled 1 x 1 layer continues as its stride-1 equivalent
 
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
@@ -1037,10 +1050,12 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     do {                                                                                                             \
         if (G.Cp <= 16)                                                                                              \
             conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems); \
+                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems, \
+                                                                      (int)G.sub, (int)G.Hs, (int)G.Ws);     \
         else                                                                                                         \
             conv_w8_prep_x_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, (int)W, \
-                                                                (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, cblocks); \
+                                                                (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, cblocks, \
+                                                                (int)G.sub, (int)G.Hs, (int)G.Ws);           \
     } while (0)
     if (x_dtype == MIQ_F32)
         MIQ_PREP(float, 2);

@@ -53,6 +53,10 @@ CASES = [
     (2, 3, 8, 8, 5, 3, 1, 1), (2, 8, 9, 11, 16, 3, 2, 1), (1, 4, 5, 5, 6, 1, 1, 0), (3, 3, 32, 32, 64, 3, 1, 1),
     (2, 64, 14, 14, 128, 3, 1, 1), (2, 3, 30, 30, 64, 7, 2, 3), (4, 16, 12, 12, 130, 1, 2, 0), (1, 70, 9, 9, 33, 3, 1, 0),
     (2, 32, 16, 16, 64, 3, 2, 1), (5, 24, 7, 7, 200, 5, 1, 2), (1, 1, 4, 4, 1, 2, 1, 0), (2, 128, 7, 7, 256, 3, 1, 1),
+    # strided 1 x 1 filters: the re-layout keeps only the pixels the filter visits (even and odd sizes, stride 3,
+    # few channels, ragged channels)
+    (2, 64, 16, 16, 128, 1, 2, 0), (3, 70, 15, 17, 20, 1, 2, 0), (2, 32, 13, 13, 8, 1, 3, 0), (1, 3, 9, 9, 4, 1, 2, 0),
+    (2, 64, 56, 56, 128, 1, 2, 0),
 ]
 
 
