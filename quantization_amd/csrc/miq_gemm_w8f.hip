@@ -751,36 +751,74 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(_Float16 v) { return static_cast<float>(v); }
 __device__ __forceinline__ float to_f32(__bf16 v) { return static_cast<float>(v); }
 
-// A workgroup moves 64 consecutive padded pixels (flat over b, hp, wp) x 64 channels through an LDS tile: reads run
-// along the pixels of one channel plane (256-byte runs), writes along the channels of one pixel (eight lanes fill a
-// pixel's 128 bytes per plane).  Border pixels and channels past Cin are written as zeros.
-template <typename T, int NP>
+// A workgroup moves 64 consecutive interior pixels (flat h * W + w of one image) x 64 channels through an LDS tile:
+// reads run along the pixels of one channel plane (16-byte vectors when VEC: H * W a multiple of the vector's
+// pixels, an aligned base and no subsampling; single elements otherwise), writes along the channels of one pixel
+// (eight lanes fill a pixel's 128 bytes per plane).  Channels past Cin are written as zeros.  The workgroups after
+// an image's `n_interior` write the zero border of its padded copy, one 16-byte store per plane and item.
+template <typename T, int NP, bool VEC>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                             uint32_t npix, int cblocks, int sub, int Hs, int Ws) {
+                                                             int cblocks, int n_interior, int n_border, int sub, int Hs, int Ws) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x;
-    const uint32_t pix0 = (blockIdx.x / cblocks) * 64u;
-    const int c0 = (blockIdx.x % cblocks) * 64;
-    {
-        const uint32_t pp = pix0 + (t & 63);
-        const uint32_t b = pp / (Hp * Wp), rem = pp - b * (Hp * Wp);
-        const int hp = rem / Wp, wp = rem - hp * Wp, h = hp - pad, w = wp - pad;
-        const bool inside = pp < npix && h >= 0 && h < H && w >= 0 && w < W;
-        // channel 0 of this pixel in the Hs x Ws source image (every sub-th pixel of every sub-th row is kept)
-        const size_t src = (static_cast<size_t>(b) * Cin * Hs + h * sub) * Ws + w * sub;
+    const uint32_t per_img = n_interior + n_border;
+    const uint32_t b = blockIdx.x / per_img;
+    const int bx = blockIdx.x - b * per_img;
+    if (bx >= n_interior) {
+        const uint32_t cgs = Cp >> 3, border = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
+        const uint32_t idx = (bx - n_interior) * 256u + t;
+        if (idx >= border * cgs) return;
+        const uint32_t e = idx / cgs, cg = idx - e * cgs;
+        uint32_t hp, wp;
+        if (e < static_cast<uint32_t>(2 * pad * Wp)) {   // full rows: the first `pad` and the last `pad`
+            const uint32_t r = e / Wp;
+            hp = r < static_cast<uint32_t>(pad) ? r : H + r;
+            wp = e - r * Wp;
+        } else {                                         // side columns of the H interior rows
+            const uint32_t q = e - 2 * pad * Wp, r = q / (2 * pad), k = q - r * 2 * pad;
+            hp = r + pad;
+            wp = k < static_cast<uint32_t>(pad) ? k : W + k;
+        }
+        uint16_t* o = xp + ((static_cast<size_t>(b) * Hp + hp) * Wp + wp) * Cp + cg * 8;
+        *reinterpret_cast<uint4*>(o) = uint4{0u, 0u, 0u, 0u};
+        if constexpr (NP == 2) *reinterpret_cast<uint4*>(o + plane_elems) = uint4{0u, 0u, 0u, 0u};
+        return;
+    }
+    const int HW = H * W;
+    const int p0 = (bx / cblocks) * 64, c0 = (bx % cblocks) * 64;
+    const size_t cstride = static_cast<size_t>(Hs) * Ws;   // elements between channel planes of the source
+    const T* xb = x + static_cast<size_t>(b) * Cin * cstride;
+    if constexpr (VEC) {
+        constexpr int V = 16 / sizeof(T);      // pixels per 16-byte load
+        constexpr int PV = 64 / V;             // loads per channel row of the tile
+#pragma unroll
+        for (int i = 0; i < (64 * PV) / 256; ++i) {
+            const int item = t + 256 * i, pv = item % PV, cl = item / PV, c = c0 + cl;
+            alignas(16) T v[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = static_cast<T>(0.0f);
+            if (c < Cin && p0 + pv * V < HW)
+                *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(xb + c * cstride + p0 + pv * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) tile[cl][pv * V + e] = to_f32(v[e]);
+        }
+    } else {
+        const int p = p0 + (t & 63);
+        const int h = p / W, w = p - h * W;
+        const size_t src = static_cast<size_t>(h * sub) * Ws + w * sub;   // every sub-th pixel of every sub-th row is kept
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cl = (t >> 6) + 4 * i, c = c0 + cl;
-            tile[cl][t & 63] = (inside && c < Cin) ? to_f32(x[src + static_cast<size_t>(c) * Hs * Ws]) : 0.0f;
+            tile[cl][t & 63] = (p < HW && c < Cin) ? to_f32(xb[src + c * cstride]) : 0.0f;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int it = t + 256 * k, pixl = it >> 3, cg = it & 7;
-        const uint32_t pp = pix0 + pixl;
-        if (pp >= npix || c0 + cg * 8 >= Cp) continue;
+        const int p = p0 + pixl;
+        if (p >= HW || c0 + cg * 8 >= Cp) continue;
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -796,7 +834,8 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
             hi[j] = pack2_bf16(fh[0], fh[1]);
             lo[j] = pack2_bf16(fl[0], fl[1]);
         }
-        uint16_t* o = xp + static_cast<size_t>(pp) * Cp + c0 + cg * 8;
+        const int h = p / W, w = p - h * W;
+        uint16_t* o = xp + ((static_cast<size_t>(b) * Hp + h + pad) * Wp + w + pad) * Cp + c0 + cg * 8;
         *reinterpret_cast<uint4*>(o) = uint4{hi[0], hi[1], hi[2], hi[3]};
         if constexpr (NP == 2) *reinterpret_cast<uint4*>(o + plane_elems) = uint4{lo[0], lo[1], lo[2], lo[3]};
     }
@@ -1040,22 +1079,31 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
     const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp);
     const int cblocks = static_cast<int>(ceil_div(G.Cp, 64));
-    const int64_t pblocks = ceil_div(npix, 64) * cblocks;
+    const int n_interior = static_cast<int>(ceil_div(H * W, 64) * cblocks);
+    const int n_border = static_cast<int>(ceil_div((2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 8), 256));
+    const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border);
     MIQ_REQUIRE(pblocks < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8: too many re-layout blocks");
     const int pgrid = static_cast<int>(pblocks);
     const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
     const int sgrid = static_cast<int>(sitems / 256 + 1 < 16384 ? sitems / 256 + 1 : 16384);
     const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
+    // 16-byte source vectors: whole vectors per channel plane, every plane 16-byte aligned, no subsampling
+    const int64_t vpix = 16 / static_cast<int64_t>(xsz);
+    const bool vec = G.sub == 1 && (H * W) % vpix == 0 && miq::aligned(x, 16);
 #define MIQ_PREP(T, NP)                                                                                              \
     do {                                                                                                             \
         if (G.Cp <= 16)                                                                                              \
             conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems, \
                                                                       (int)G.sub, (int)G.Hs, (int)G.Ws);     \
+        else if (vec)                                                                                                \
+            conv_w8_prep_x_kernel<T, NP, true><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                      n_interior, n_border, 1, (int)G.Hs, (int)G.Ws); \
         else                                                                                                         \
-            conv_w8_prep_x_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, (int)W, \
-                                                                (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, cblocks, \
-                                                                (int)G.sub, (int)G.Hs, (int)G.Ws);           \
+            conv_w8_prep_x_kernel<T, NP, false><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                       n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws); \
     } while (0)
     if (x_dtype == MIQ_F32)
         MIQ_PREP(float, 2);
