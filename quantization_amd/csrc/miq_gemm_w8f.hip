@@ -751,20 +751,52 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(_Float16 v) { return static_cast<float>(v); }
 __device__ __forceinline__ float to_f32(__bf16 v) { return static_cast<float>(v); }
 
+// OIHW int8 -> wp[Cout][KH][Lp], (kw, c) order inside a filter row, zero where padded.
+__device__ __forceinline__ void conv_w8_pack_w_items(const int8_t* __restrict__ w, int8_t* __restrict__ wp, uint32_t total,
+                                                     int Cin, int KH, int KW, int Cp, int L, int Lp, uint32_t first,
+                                                     uint32_t step) {
+    for (uint32_t idx = first; idx < total; idx += step) {
+        const uint32_t row = idx / Lp, l = idx - row * Lp, n = row / KH, kh = row - n * KH;
+        int8_t v = 0;
+        if (l < static_cast<uint32_t>(L)) {
+            const uint32_t kw = l / Cp, c = l - kw * Cp;
+            if (c < static_cast<uint32_t>(Cin)) v = w[((static_cast<size_t>(n) * Cin + c) * KH + kh) * KW + kw];
+        }
+        wp[idx] = v;
+    }
+}
+
+// What rides along with the activation re-layout: the weight re-layout, shared by the n_wpack workgroups that
+// follow every image's interior and border workgroups.
+struct ConvW8PackArgs {
+    const int8_t* w;
+    int8_t* wp;
+    uint32_t total;
+    int n_wpack, KH, KW, L, Lp;
+};
+
 // A workgroup moves 64 consecutive interior pixels (flat h * W + w of one image) x 64 channels through an LDS tile:
 // reads run along the pixels of one channel plane (16-byte vectors when VEC: H * W a multiple of the vector's
 // pixels, an aligned base and no subsampling; single elements otherwise), writes along the channels of one pixel
 // (eight lanes fill a pixel's 128 bytes per plane).  Channels past Cin are written as zeros.  The workgroups after
-// an image's `n_interior` write the zero border of its padded copy, one 16-byte store per plane and item.
+// an image's `n_interior` write the zero border of its padded copy, one 16-byte store per plane and item, and the
+// `n_wpack` after those the packed weights.
 template <typename T, int NP, bool VEC>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
-                                                             int cblocks, int n_interior, int n_border, int sub, int Hs, int Ws) {
+                                                             int cblocks, int n_interior, int n_border, int sub, int Hs, int Ws,
+                                                             ConvW8PackArgs pk) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x;
-    const uint32_t per_img = n_interior + n_border;
+    const uint32_t per_img = n_interior + n_border + pk.n_wpack;
     const uint32_t b = blockIdx.x / per_img;
     const int bx = blockIdx.x - b * per_img;
+    if (bx >= n_interior + n_border) {
+        const uint32_t nimg = gridDim.x / per_img;
+        conv_w8_pack_w_items(pk.w, pk.wp, pk.total, Cin, pk.KH, pk.KW, Cp, pk.L, pk.Lp,
+                             (b * pk.n_wpack + (bx - n_interior - n_border)) * 256u + t, nimg * pk.n_wpack * 256u);
+        return;
+    }
     if (bx >= n_interior) {
         const uint32_t cgs = Cp >> 3, border = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
         const uint32_t idx = (bx - n_interior) * 256u + t;
@@ -880,18 +912,9 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_small_kernel(const T* __re
     }
 }
 
-// OIHW int8 -> wp[Cout][KH][Lp], (kw, c) order inside a filter row, zero where padded.
 __global__ __launch_bounds__(256) void conv_w8_pack_w_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp, uint32_t total,
                                                              int Cin, int KH, int KW, int Cp, int L, int Lp) {
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += 256u * gridDim.x) {
-        const uint32_t row = idx / Lp, l = idx - row * Lp, n = row / KH, kh = row - n * KH;
-        int8_t v = 0;
-        if (l < static_cast<uint32_t>(L)) {
-            const uint32_t kw = l / Cp, c = l - kw * Cp;
-            if (c < static_cast<uint32_t>(Cin)) v = w[((static_cast<size_t>(n) * Cin + c) * KH + kh) * KW + kw];
-        }
-        wp[idx] = v;
-    }
+    conv_w8_pack_w_items(w, wp, total, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256u + threadIdx.x, 256u * gridDim.x);
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int DEPTH = 0, int BM = 128>
@@ -1081,7 +1104,12 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     const int cblocks = static_cast<int>(ceil_div(G.Cp, 64));
     const int n_interior = static_cast<int>(ceil_div(H * W, 64) * cblocks);
     const int n_border = static_cast<int>(ceil_div((2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 8), 256));
-    const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border);
+    const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
+    // about four weight bytes per thread, spread over the images
+    const bool pack_along = G.Cp > 16;
+    ConvW8PackArgs pk{w, wp, wtotal, 0, (int)KH, (int)KW, (int)G.L, (int)G.Lp};
+    if (pack_along) pk.n_wpack = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(ceil_div(wtotal, 1024), B), 1), 4096));
+    const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border + pk.n_wpack);
     MIQ_REQUIRE(pblocks < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8: too many re-layout blocks");
     const int pgrid = static_cast<int>(pblocks);
     const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
@@ -1099,11 +1127,11 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
         else if (vec)                                                                                                \
             conv_w8_prep_x_kernel<T, NP, true><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                      n_interior, n_border, 1, (int)G.Hs, (int)G.Ws); \
+                                                                      n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
         else                                                                                                         \
             conv_w8_prep_x_kernel<T, NP, false><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
                                                                        (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                       n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws); \
+                                                                       n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws, pk); \
     } while (0)
     if (x_dtype == MIQ_F32)
         MIQ_PREP(float, 2);
@@ -1113,10 +1141,11 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
         MIQ_PREP(__bf16, 1);
 #undef MIQ_PREP
     if (int rc = check_launch("conv_w8_prep_x_kernel")) return rc;
-    const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
-    conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
-        w, wp, wtotal, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L, (int)G.Lp);
-    if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
+    if (!pack_along) {
+        conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
+            w, wp, wtotal, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L, (int)G.Lp);
+        if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
+    }
 
     W8fArgs g{xp, wp, bias, alpha, out, beta, static_cast<int>(G.M), static_cast<int>(Cout), static_cast<int>(G.K),
               static_cast<uint32_t>(G.plane_bytes), 0, 0, 0,
