@@ -152,7 +152,7 @@ int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t 
  * groups 1, one stride and one padding for both axes, zero padding.  Output size as F.conv2d:
  * Ho = (H + 2*pad - KH) / stride + 1.
  * workspace: at least miq_conv2d_w8_workspace(...) bytes, 256-byte aligned (padded channels-last planes of x
- * and the re-laid weight). */
+ * and the re-laid weight; for a 1 x 1 filter with a stride and no padding only the pixels the filter visits). */
 size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
                                int64_t KW, int64_t stride, int64_t pad);
 int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
@@ -175,7 +175,8 @@ int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst,
  * the stride; its own test compares with F.conv2d).  Dilation 1, groups 1, square stride
  * and padding, as the reference kernel.
  * workspace: at least miq_conv2d_i8_workspace(...) bytes, 256-byte aligned: holds the
- * zero-padded channels-last copy of x and the re-laid weight.
+ * zero-padded channels-last copy of x and the re-laid weight (for a 1 x 1 filter with a stride
+ * and no padding only the pixels the filter visits).
  */
 size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
                                int64_t KW, int64_t stride, int64_t pad);

@@ -59,6 +59,15 @@ def test_argument_validation_needs_no_device():
     assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 64, 3, 3, 1, 1) == 256 * 58 * 60 * 64 + 9 * 4 * 64 * 16
     # any other layer: 256 x (58*58*64) padded channels-last activations + 128 x (3*192) packed weights
     assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 128, 3, 3, 2, 1) == 256 * 58 * 58 * 64 + 128 * 576
+    # a strided 1 x 1 layer keeps only the pixels it visits: the workspace of its stride-1 equivalent on 28 x 28
+    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 128, 1, 1, 2, 0) == 256 * 28 * 28 * 64 + 128 * 64
+    assert lib.miq_conv2d_i8_workspace(256, 64, 56, 56, 128, 1, 1, 2, 0) == \
+        lib.miq_conv2d_i8_workspace(256, 64, 28, 28, 128, 1, 1, 1, 0)
+    assert lib.miq_conv2d_i8_workspace(2, 16, 15, 17, 8, 1, 1, 3, 0) == lib.miq_conv2d_i8_workspace(2, 16, 5, 6, 8, 1, 1, 1, 0)
+    assert lib.miq_conv2d_w8_workspace(0, 4, 64, 56, 56, 128, 1, 1, 2, 0) == \
+        lib.miq_conv2d_w8_workspace(0, 4, 64, 28, 28, 128, 1, 1, 1, 0)
+    # ... but not with padding or a larger filter
+    assert lib.miq_conv2d_i8_workspace(2, 64, 56, 56, 128, 1, 1, 2, 1) == 2 * 58 * 58 * 64 + 128 * 64
     # zero-sized problems succeed without touching a device
     assert lib.miq_gemm_i8(null, null, 0, 0, 8, 16, null, null, 0.0, null, 3, null, 0, null) == 0
     assert lib.miq_quantize_rows_sym_i8(null, 0, 0, 16, null, null, null, null, null) == 0
