@@ -942,6 +942,10 @@ int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
             case 'c': return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 64>(g, st);        // 64 x 64, double-buffered
             case 'd': return launch_conv_w8f<128, 2, 2, NP, OUT, 2, 64>(g, st);       // 64 x 128, double-buffered
             case 'e': return launch_conv_w8f<64, 2, 2, NP, OUT, 0, 64>(g, st);        // 64 x 64, deepest ring
+            case 'f': return launch_conv_w8f<256, 2, 4, NP, OUT, 2, 64>(g, st);       // 64 x 256, double-buffered
+            case 'g':                                                                 // 128 x 256, one plane only
+                if constexpr (NP == 1) return launch_conv_w8f<256, 2, 4, NP, OUT, 2>(g, st);
+                break;
             default: break;
         }
     }
@@ -951,6 +955,12 @@ int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
     if (g.N <= 64) {
         if constexpr (NP == 1) return launch_conv_w8f<64, 2, 2, NP, OUT, 2>(g, st);
         return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 64>(g, st);
+    }
+    // One plane and more than 128 output channels: 128 x 256 tiles halve the passes over the expanded activations,
+    // which is what bounds these layers (ResNet-18 at batch 256, bf16: 256->256 14x14 128 -> 112 us, 512->512 7x7
+    // 113 -> 99 us, 128->256 3x3/2 89 -> 77 us), once there are tiles for most CUs.  Two planes would need 192 KiB.
+    if constexpr (NP == 1) {
+        if (g.N > 128 && ceil_div(g.M, 128) * ceil_div(g.N, 256) >= 160) return launch_conv_w8f<256, 2, 4, NP, OUT, 2>(g, st);
     }
     return launch_conv_w8f<128, 2, 4, NP, OUT>(g, st);
 }

@@ -76,6 +76,15 @@ def test_conv_w8_resnet_layer(N):
     check(N, 32, 128, 28, 28, 128, 3, 1, 1, "bf16", seed=10)
 
 
+def test_conv_w8_wide_tiles_one_plane(N):
+    """bf16 activations, more than 128 output channels and tiles for most CUs: the 128 x 256 tiles (ragged channel
+    counts, one and two tile columns, stride 1 and 2, fp32 and bf16 outputs); fp32 activations stay on 128 x 128."""
+    check(N, 32, 128, 28, 28, 200, 3, 1, 1, "bf16", seed=11)
+    check(N, 64, 64, 40, 40, 300, 3, 2, 1, "bf16", seed=12, out_dtype=torch.bfloat16, beta=0.25)
+    check(N, 48, 32, 23, 23, 256, 1, 1, 0, "bf16", seed=13, bias=False)
+    check(N, 32, 128, 28, 28, 200, 3, 1, 1, "f32", seed=14)
+
+
 @pytest.mark.parametrize("case", [c for c in FW.cases() if c.startswith("conv")])
 def test_conv_w8_golden_layer_forward(N, case):
     """The reference's Quantizer.forward outputs for Conv2d layers (integer-valued float activations: every product

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization_amd import _native as N
 def timed(fn, iters=10):
     for _ in range(2): fn()
@@ -11,14 +11,14 @@ def timed(fn, iters=10):
 spin = torch.randn(4096, 4096, device="cuda")
 for _ in range(100): spin @ spin
 for dt in (torch.bfloat16, torch.float32):
-    for B, C, H, Co, k, s, p in [(256, 64, 56, 64, 3, 1, 1), (256, 64, 56, 128, 3, 2, 1), (256, 128, 28, 128, 3, 1, 1), (256, 256, 14, 256, 3, 1, 1), (256, 512, 7, 512, 3, 1, 1), (256, 3, 224, 64, 7, 2, 3)]:
+    for B, C, H, Co, k, s, p in [(256, 64, 56, 64, 3, 1, 1), (256, 64, 56, 128, 3, 2, 1), (256, 128, 28, 128, 3, 1, 1), (256, 128, 28, 256, 3, 2, 1), (256, 256, 14, 256, 3, 1, 1), (256, 256, 14, 512, 3, 2, 1), (256, 512, 7, 512, 3, 1, 1), (256, 3, 224, 64, 7, 2, 3)][int(sys.argv[2]) if len(sys.argv) > 2 else 0:]:
         x = torch.randn(B, C, H, H, device="cuda").to(dt)
         w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device="cuda").to(torch.int8)
         alpha = torch.rand(Co, device="cuda") * 0.01
         fn = lambda: N.conv2d_w8(x, w, s, p, alpha=alpha)
         res = {}
         for _ in range(3):
-            for v in ("0", "a", "b", "c", "d", "e"):
+            for v in (sys.argv[1] if len(sys.argv) > 1 else "0abcde"):
                 os.environ["MIQ_CONV_W8_TILE"] = v
                 res.setdefault(v, []).append(timed(fn))
         print(f"{str(dt).split('.')[-1]:8s} {C}->{Co} {H}x{H} k{k}s{s}: default " + " | ".join(f"{v} {sorted(t)[1]:6.1f}" for v, t in res.items()), flush=True)
