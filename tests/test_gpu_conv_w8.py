@@ -76,6 +76,15 @@ def test_conv_w8_resnet_layer(N):
     check(N, 32, 128, 28, 28, 128, 3, 1, 1, "bf16", seed=10)
 
 
+def test_conv_w8_1x1_strided_random_shapes(N):
+    """Seeded random 1 x 1 layers with stride 2..4 (the subsampling re-layout) on all three activation types."""
+    rng = np.random.default_rng(78)
+    for i in range(15):
+        C, Co = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        check(N, int(rng.integers(1, 4)), C, H, W, Co, 1, int(rng.integers(2, 5)), 0, ("f32", "bf16", "f16")[i % 3], seed=100 + i)
+
+
 def test_conv_w8_wide_tiles_one_plane(N):
     """bf16 activations, more than 128 output channels and tiles for most CUs: the 128 x 256 tiles (ragged channel
     counts, one and two tile columns, stride 1 and 2, fp32 and bf16 outputs); fp32 activations stay on 128 x 128."""

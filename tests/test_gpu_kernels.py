@@ -301,6 +301,23 @@ def test_conv_3x3_random_shapes_vs_torch(N):
         assert torch.equal(out, ref), (B, C, H, W, Co, pad)
 
 
+def test_conv_1x1_strided_random_shapes_vs_torch(N):
+    """Seeded random 1 x 1 layers with stride 2..4 and no padding (the subsampling re-layout: aligned 8-byte runs,
+    single bytes, ragged channels and pixel tiles) and with padding (the whole image re-laid) against F.conv2d in
+    float64, exact on these integers."""
+    rng = np.random.default_rng(77)
+    for i in range(24):
+        C, Co = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        H, W = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        if i % 3 == 0:
+            H, W = 8 * int(rng.integers(1, 7)), 8 * int(rng.integers(1, 7))
+        s, pad, B = int(rng.integers(2, 5)), int(i % 8 == 7), int(rng.integers(1, 5))
+        x, w = rand_i8((B, C, H, W), 3 * i + 1), rand_i8((Co, C, 1, 1), 3 * i + 2)
+        ref = torch.nn.functional.conv2d(x.cuda().double(), w.cuda().double(), stride=s, padding=pad).to(torch.int32)
+        out = N.conv2d_i8(x.cuda(), w.cuda(), s, pad, out_dtype=torch.int32)
+        assert out.shape == ref.shape and torch.equal(out, ref), (B, C, H, W, Co, s, pad)
+
+
 def test_conv_resnet_layer_vs_torch(N):
     """A ResNet-18 layer1 shape at a small batch, checked against F.conv2d in float64."""
     x, w = rand_i8((4, 64, 56, 56), 1), rand_i8((64, 64, 3, 3), 2)
