@@ -776,12 +776,12 @@ struct ConvW8PackArgs {
 };
 
 // A workgroup moves 64 consecutive interior pixels (flat h * W + w of one image) x 64 channels through an LDS tile:
-// reads run along the pixels of one channel plane (16-byte vectors when VEC: H * W a multiple of the vector's
+// reads run along the pixels of one channel plane (VB-byte vectors, 16 or 8, when VB != 0: H * W a multiple of the vector's
 // pixels, an aligned base and no subsampling; single elements otherwise), writes along the channels of one pixel
 // (eight lanes fill a pixel's 128 bytes per plane).  Channels past Cin are written as zeros.  The workgroups after
 // an image's `n_interior` write the zero border of its padded copy, one 16-byte store per plane and item, and the
 // `n_wpack` after those the packed weights.
-template <typename T, int NP, bool VEC>
+template <typename T, int NP, int VB>
 __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, uint32_t plane_elems,
                                                              int Cin, int H, int W, int Hp, int Wp, int Cp, int pad,
                                                              int cblocks, int n_interior, int n_border, int sub, int Hs, int Ws,
@@ -821,8 +821,9 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
     const int p0 = (bx / cblocks) * 64, c0 = (bx % cblocks) * 64;
     const size_t cstride = static_cast<size_t>(Hs) * Ws;   // elements between channel planes of the source
     const T* xb = x + static_cast<size_t>(b) * Cin * cstride;
-    if constexpr (VEC) {
-        constexpr int V = 16 / sizeof(T);      // pixels per 16-byte load
+    if constexpr (VB != 0) {
+        typedef uint32_t vecw __attribute__((ext_vector_type(VB / 4)));
+        constexpr int V = VB / sizeof(T);      // pixels per load
         constexpr int PV = 64 / V;             // loads per channel row of the tile
 #pragma unroll
         for (int i = 0; i < (64 * PV) / 256; ++i) {
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < V; ++e) v[e] = static_cast<T>(0.0f);
             if (c < Cin && p0 + pv * V < HW)
-                *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(xb + c * cstride + p0 + pv * V);
+                *reinterpret_cast<vecw*>(v) = *reinterpret_cast<const vecw*>(xb + c * cstride + p0 + pv * V);
 #pragma unroll
             for (int e = 0; e < V; ++e) tile[cl][pv * V + e] = to_f32(v[e]);
         }
@@ -1125,21 +1126,27 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
     const int sgrid = static_cast<int>(sitems / 256 + 1 < 16384 ? sitems / 256 + 1 : 16384);
     const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
-    // 16-byte source vectors: whole vectors per channel plane, every plane 16-byte aligned, no subsampling
-    const int64_t vpix = 16 / static_cast<int64_t>(xsz);
-    const bool vec = G.sub == 1 && (H * W) % vpix == 0 && miq::aligned(x, 16);
+    // 16- or 8-byte source vectors: whole vectors per channel plane, every plane aligned to them, no subsampling
+    const int64_t plane_b = H * W * static_cast<int64_t>(xsz);
+    const bool vec16 = G.sub == 1 && plane_b % 16 == 0 && miq::aligned(x, 16);
+    const char* v8 = dev_switch("MIQ_CONV_W8_VEC8");   // developer A/B switch: 0 = single elements instead of 8-byte vectors
+    const bool vec8 = G.sub == 1 && plane_b % 8 == 0 && miq::aligned(x, 8) && !(v8 && v8[0] == '0');
 #define MIQ_PREP(T, NP)                                                                                              \
     do {                                                                                                             \
         if (G.Cp <= 16)                                                                                              \
             conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems, \
                                                                       (int)G.sub, (int)G.Hs, (int)G.Ws);     \
-        else if (vec)                                                                                                \
-            conv_w8_prep_x_kernel<T, NP, true><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                      n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
+        else if (vec16)                                                                                              \
+            conv_w8_prep_x_kernel<T, NP, 16><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                    (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                    n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
+        else if (vec8)                                                                                               \
+            conv_w8_prep_x_kernel<T, NP, 8><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                   (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                   n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
         else                                                                                                         \
-            conv_w8_prep_x_kernel<T, NP, false><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+            conv_w8_prep_x_kernel<T, NP, 0><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
                                                                        (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
                                                                        n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws, pk); \
     } while (0)

@@ -57,6 +57,8 @@ CASES = [
     # few channels, ragged channels)
     (2, 64, 16, 16, 128, 1, 2, 0), (3, 70, 15, 17, 20, 1, 2, 0), (2, 32, 13, 13, 8, 1, 3, 0), (1, 3, 9, 9, 4, 1, 2, 0),
     (2, 64, 56, 56, 128, 1, 2, 0),
+    # channel planes that are whole 8-byte but not 16-byte vectors (fp32: H * W even, not a multiple of 4)
+    (2, 24, 6, 7, 40, 3, 1, 1), (1, 40, 10, 9, 16, 3, 1, 1),
 ]
 
 

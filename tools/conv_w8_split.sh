@@ -1,6 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for cfg in "256 64 56 64 3 1 1 f32" "256 64 56 64 3 1 1 bf16" "256 128 28 128 3 1 1 f32" "256 3 224 64 7 2 3 f32" "256 512 7 512 3 1 1 f32"; do
+# usage: conv_w8_split.sh ["B Cin H Cout k s p dtype" ...]   (default: five ResNet-18 layers at batch 256)
+if [ $# -eq 0 ]; then set -- "256 64 56 64 3 1 1 f32" "256 64 56 64 3 1 1 bf16" "256 128 28 128 3 1 1 f32" "256 3 224 64 7 2 3 f32" "256 512 7 512 3 1 1 f32"; fi
+for cfg in "$@"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pw8_$tag -o t -- python3 $R/tools/conv_w8_probe.py $cfg 20 > /dev/null 2>&1 || exit 1
   echo "== $cfg"; 
