@@ -85,6 +85,41 @@ def weight_only_float(N_, dev):
     return res
 
 
+def conv_int8(N_, dev):
+    """The int8 Conv2d (miq_conv2d_i8) on two ResNet-18 layers at batch 256, int32 out: whole call (re-layout
+    launch + implicit-GEMM kernel), HIP events per call, outputs rotating over three buffers.  The large-image
+    layer is priced against HBM bandwidth on its algorithmic bytes (int8 input and weight once + the int32
+    output), the 14 x 14 layer against the dense int8 MFMA peak on 2*B*Cout*Ho*Wo*Cin*9."""
+    res = {"batch": 256, "out_dtype": "int32"}
+    for C, H, Co, bound in ((64, 56, 64, "hbm"), (256, 14, 256, "mfma")):
+        x = torch.randint(-128, 128, (256, C, H, H), dtype=torch.int32, device=dev).to(torch.int8)
+        w = torch.randint(-128, 128, (Co, C, 3, 3), dtype=torch.int32, device=dev).to(torch.int8)
+        outs = [torch.empty(256, Co, H, H, dtype=torch.int32, device=dev) for _ in range(3)]
+        it = [0]
+
+        def step():
+            N_.conv2d_i8(x, w, 1, 1, out_dtype=torch.int32, out=outs[it[0] % 3])
+            it[0] += 1
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        ts = sorted(event_times(step, 50))
+        ms = ts[len(ts) // 2]
+        ops = 2.0 * 256 * Co * H * H * C * 9
+        nbytes = x.numel() + w.numel() + 4 * outs[0].numel()
+        entry = {"call_ms": round(ms, 4), "TOPS": round(ops / (ms * 1e-3) / 1e12, 1)}
+        if bound == "hbm":
+            entry["roofline"] = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "algorithmic_bytes": nbytes}
+        else:
+            entry["roofline"] = {"bound": "mfma", "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": PEAK_INT8_TOPS,
+                                 "unit": "TFLOP/s", "frac": round(ops / (ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4)}
+        res[f"{C}to{Co}_{H}x{H}_k3s1"] = entry
+        del x, w, outs
+    return res
+
+
 def cpu_baseline(K, N, sample_rows, seed):
     """Reference CPU path on a bounded sample: quantize a [1024, K] slab of the weight with the
     reference's row loop, then weight-only forward of `sample_rows` rows against the full weight."""
@@ -300,6 +335,7 @@ def main():
             }
         if world == 1:
             line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
+            line["extra"]["conv_int8"] = conv_int8(N_, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)
