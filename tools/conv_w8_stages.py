@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Tile sweep of miq_conv2d_w8 on ResNet-18 layers at batch 256 (developer switch MIQ_CONV_W8_TILE: a = 128x64,
+b = 128x128, c = 64x64, d = 64x128, e = 64x64 deepest ring, f = 64x256, g = 128x256 one plane only, 0 = the library's own
+choice): whole calls, median of 3 interleaved rounds, bf16 then fp32 activations.
+
+    python tools/conv_w8_stages.py [variants, default 0abcde] [index of the first layer of the list]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization_amd import _native as N
