@@ -111,6 +111,9 @@ def wo_forward_cases(mods):
         "conv_3_5_p1": (torch.nn.Conv2d(3, 5, 3, padding=1), (2, 3, 8, 8)),
         "conv_8_16_s2": (torch.nn.Conv2d(8, 16, 3, stride=2, padding=1), (2, 8, 9, 11)),
         "conv_4_6_1x1_nobias": (torch.nn.Conv2d(4, 6, 1, bias=False), (1, 4, 5, 5)),
+        # strided 1 x 1 layers (appended last: the cases above keep their random draws)
+        "conv_12_20_1x1_s2_nobias": (torch.nn.Conv2d(12, 20, 1, stride=2, bias=False), (2, 12, 9, 16)),
+        "conv_5_7_1x1_s3": (torch.nn.Conv2d(5, 7, 1, stride=3), (2, 5, 10, 11)),
     }
     for name, (mod, xshape) in cases.items():
         ql = Quantizer.from_float(module=mod, data_metry=Q_PARAMS, quantize_output=False)
@@ -260,6 +263,9 @@ def wo_forward_float_cases(mods):
         "f32_conv_8_16_s2": (torch.nn.Conv2d(8, 16, 3, stride=2, padding=1), (2, 8, 9, 11), torch.float32, 3.0),
         "f32_conv_20_40_1x1_nobias": (torch.nn.Conv2d(20, 40, 1, bias=False), (3, 20, 5, 5), torch.float32, 1.0),
         "f32_conv_16_24_5x5": (torch.nn.Conv2d(16, 24, 5, padding=2), (2, 16, 12, 12), torch.float32, 0.2),
+        # strided 1 x 1 layers (appended last: the cases above keep their random draws)
+        "f32_conv_24_40_1x1_s2": (torch.nn.Conv2d(24, 40, 1, stride=2), (2, 24, 9, 16), torch.float32, 1.0),
+        "f32_conv_20_9_1x1_s3_nobias": (torch.nn.Conv2d(20, 9, 1, stride=3, bias=False), (2, 20, 10, 11), torch.float32, 2.0),
     }
     for name, (mod, xshape, dt, mag) in cases.items():
         ql = Quantizer.from_float(module=mod, data_metry=Q_PARAMS, quantize_output=False)
@@ -286,6 +292,11 @@ def main():
         wo = load_ref("Weight_Only")
         np.savez_compressed(os.path.join(OUT, "wo_forward_float.npz"), **wo_forward_float_cases(wo))
         print("wo_forward_float.npz", os.path.getsize(os.path.join(OUT, "wo_forward_float.npz")))
+        return
+    if sys.argv[1:] == ["wo_forward"]:
+        wo = load_ref("Weight_Only")
+        np.savez_compressed(os.path.join(OUT, "wo_forward.npz"), **wo_forward_cases(wo))
+        print("wo_forward.npz", os.path.getsize(os.path.join(OUT, "wo_forward.npz")))
         return
     if sys.argv[1:] == ["pools"]:
         wa = load_ref("Weight_Activation")
