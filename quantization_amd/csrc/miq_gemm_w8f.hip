@@ -630,6 +630,14 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
         if (splits > 32) splits = 32;
         if (splits < 1) splits = 1;
     }
+    // Two planes at M <= 16 with a grid that covers most CUs once: every workgroup is bound by what one workgroup can
+    // pull through the LDS-DMA, and a second one per CU on half of K gains more than the slab reduction costs
+    // ([14336,4096] fp32, M = 16: 22.5 -> 18.6 us; one plane loses: 13.2 -> 15.6 us; three or four slices gain less).
+    if (planes == 2 && p.bm == 16 && tiles >= 160 && tiles <= 256 && nt >= 16 && resident >= 2 * tiles) splits = 2;
+    if (const char* t = dev_switch("MIQ_W8F_SPLITS")) {   // developer A/B switch: force the number of K slices
+        const int64_t f = atoi(t);
+        if (f >= 1 && f <= 32 && f <= nt) splits = f;
+    }
     if (splits > 1) {
         p.kt_per_split = static_cast<int>(ceil_div(nt, splits));
         p.splits = static_cast<int>(ceil_div(nt, p.kt_per_split));
