@@ -1,9 +1,14 @@
 """Builds quantization_amd/libmiq.so (the HIP kernels + C ABI) for gfx950 with hipcc.
 
-    python -m quantization_amd.build [--force]
+    python -m quantization_amd.build [--force] [--dev]
 
 hipcc cross-compiles without a GPU.  The .so is built in-tree next to this file so that it
 travels with the source tree; it is never installed into site-packages.
+
+libmiq.so, the product, is compiled with -DMIQ_NO_DEV_SWITCHES: it reads no environment variable
+and holds no timing-only kernel.  --dev also builds libmiq_dev.so from the same sources without
+that define: the developer A/B switches (MIQ_GEMM_*, MIQ_CONV_*, ...) and the ablation builds of
+the GEMM kernel, which tools/ load through tools/_devlib.py.  Nothing in the package loads it.
 """
 import os
 import subprocess
@@ -13,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmiq.so")
+DEV_LIB = os.path.join(HERE, "libmiq_dev.so")
 SOURCES = ["miq_api.hip", "miq_quantize.hip", "miq_gemm_i8.hip", "miq_gemm_w8f.hip", "miq_conv2d_i8.hip", "miq_pool.hip", "miq_activation.hip"]
 HEADERS = ["miq_common.h", "miq_gemm_core.h"]
 
@@ -39,10 +45,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile each source to an object (in csrc/build/) and link libmiq.so.  Returns its path."""
-    objdir = os.path.join(CSRC, "build")
+def build(force=False, verbose=False, dev=False):
+    """Compile each source to an object (in csrc/build/) and link libmiq.so (dev=True: libmiq_dev.so, with
+    the developer switches).  Returns the library's path."""
+    objdir = os.path.join(CSRC, "build", "dev" if dev else "product")
     os.makedirs(objdir, exist_ok=True)
+    lib = DEV_LIB if dev else LIB
+    flags = FLAGS + ([] if dev else ["-DMIQ_NO_DEV_SWITCHES"])
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "miq.h"), __file__]
     objs, procs = [], []
     for src in SOURCES:
@@ -50,20 +59,22 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + common):
-            cmd = [hipcc()] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc()] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))

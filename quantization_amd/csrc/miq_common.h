@@ -17,8 +17,11 @@ int fail(int code, const char* fmt, ...);
 
 // Developer A/B switches (tile shapes, kernel variants, timing-only builds: what tools/*_ab.py and the
 // ablation tables under profiles/ are made with) are environment variables read per call through this one
-// function.  They choose between kernels that all compute the same result; a build with
-// -DMIQ_NO_DEV_SWITCHES ignores them all.
+// function.  Most choose between kernels that compute the same result; MIQ_GEMM_ABL selects timing-only
+// builds of the GEMM kernel that leave work out and return WRONG results.  The product library is compiled
+// with -DMIQ_NO_DEV_SWITCHES: this function then returns nullptr without reading the environment, and the
+// timing-only kernels are not instantiated.  Only libmiq_dev.so (python -m quantization_amd.build --dev),
+// which tools/ load, honours the switches.
 inline const char* dev_switch(const char* name) {
 #ifdef MIQ_NO_DEV_SWITCHES
     (void)name;

@@ -43,6 +43,14 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, ui
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voffset, 0, 0, 0);
 }
 
+// The same with a wave-uniform byte offset added in the scalar operand of the instruction: a lane's
+// `voffset` can then stay fixed for a whole kernel while the K-tile and the row group advance in
+// scalar registers.  The range check covers `voffset` only (the scalar offset is not part of it), so
+// this form is for tiles that lie wholly inside their matrix.
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* dst, uint32_t voffset, uint32_t soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voffset, soffset, 0, 0);
+}
+
 // Byte offset, inside a rows x 128 B tile, of logical chunk `c` (0..7) of row `r`.
 __device__ __forceinline__ int tile_offset(int r, int c) {
     return r * kTileK + ((c ^ ((r >> 1) & 7)) * kChunk);
@@ -119,20 +127,20 @@ __device__ __forceinline__ float dequant1(float acc, float bias, float alpha, fl
     return __fadd_rn(__fmul_rn(__fadd_rn(acc, bias), alpha), beta);
 }
 
-// Epilogue of a 256 x 256 tile held as acc[qm][qn][i][j] by 8 waves (2 x 4), int32 or fp32 accumulators
-// (Args: a kernel argument block with M, N, bias, alpha, beta, out).  D[i][j] of a fragment:
-// i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
+// Epilogue of a 256 x (QN * 128) tile held as acc[qm][qn][i][j] by 8 waves (2 x 4), int32 or fp32 accumulators
+// (Args: a kernel argument block with M, N, ldc, bias, alpha, beta, out; ldc = elements between two output
+// rows).  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
 //
 // bf16 outputs: a lane's four channels of one fragment are only 8 bytes, so the fragments j = 0, 1 of a
 // row group (channels 0-15 and 16-31 of the wave's 32) first trade 16-lane rows (pair_rows_bf16); every
 // lane then stores eight consecutive channels as one 16-byte vector: half the store instructions, and a
 // row's 32 channels leave as one 64-byte segment.
-template <int OUT, bool NT = true, bool WIDE16 = true, typename Args, typename V4>
-__device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2][2][4][2], int m0, int n0, int wm,
+template <int OUT, bool NT = true, bool WIDE16 = true, int QN = 2, typename Args, typename V4>
+__device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2][QN][4][2], int m0, int n0, int wm,
                                                int wn, int lane) {
-    const bool vec_ok = (g.N & 3) == 0;
+    const bool vec_ok = (g.ldc & 3) == 0;
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn) {
+    for (int qn = 0; qn < QN; ++qn) {
         const int nb = n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
         float al[2][4], bi[2][4];
 #pragma unroll
@@ -151,7 +159,7 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
             }
         }
         if constexpr (OUT == kOutBF16 && WIDE16) {
-            if ((g.N & 7) == 0 && nb + 32 <= g.N) {   // wave-uniform
+            if ((g.ldc & 7) == 0 && nb + 32 <= g.N) {   // wave-uniform
                 const int n = nb + paired_offset(lane);
 #pragma unroll
                 for (int qm = 0; qm < 2; ++qm)
@@ -167,7 +175,7 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                         const v4i v = pair_rows_bf16(p[0], p[1]);
                         const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
                         if (m >= g.M) continue;
-                        v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) + static_cast<size_t>(m) * g.N + n);
+                        v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) + static_cast<size_t>(m) * g.ldc + n);
                         if constexpr (NT) {
                             __builtin_nontemporal_store(v, o);
                         } else {
@@ -187,7 +195,7 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                     const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
                     if (m >= g.M || n >= g.N) continue;
                     const V4 a = acc[qm][qn][i][j];
-                    const size_t idx = static_cast<size_t>(m) * g.N + n;
+                    const size_t idx = static_cast<size_t>(m) * g.ldc + n;
                     if constexpr (OUT == kOutI32) {
                         int* o = static_cast<int*>(g.out) + idx;
                         if (vec_ok && n + 3 < g.N) {

@@ -25,6 +25,7 @@ struct GemmArgs {
     void* out;
     float beta;
     int M, N, K;
+    int ldc;           // elements between two rows of `out` (N, or the full width when this is a column block)
     int tiles_m, tiles_n;
     int kt_per_split;  // K-tiles each blockIdx.y slice sums (split-K: raw int32 slabs out); 0 = all of K
     unsigned* stamps;  // timing-only builds: per-wave cycle totals of the main loop's segments
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     const int nt_all = (g.K + kTileK - 1) / kTileK;
     const int kt0 = g.kt_per_split ? static_cast<int>(blockIdx.y) * g.kt_per_split : 0;
     const int nt = g.kt_per_split ? (nt_all - kt0 < g.kt_per_split ? nt_all - kt0 : g.kt_per_split) : nt_all;
-    if (g.kt_per_split) g.out = static_cast<int*>(g.out) + static_cast<size_t>(blockIdx.y) * g.M * g.N;
+    if (g.kt_per_split) {   // slabs are dense [splits][M][N]
+        g.out = static_cast<int*>(g.out) + static_cast<size_t>(blockIdx.y) * g.M * g.N;
+        g.ldc = g.N;
+    }
     const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
 
     auto stage = [&](char* buf, int kt) {
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
     // Epilogue.  D[i][j] of a fragment: i = 4*(lane>>4) + reg -> output channel, j = lane&15 -> row.
     const int mrow = m0 + wm * WM + (lane & 15);
     const int ncol = n0 + wn * WN + (lane >> 4) * 4;
-    const bool vec_ok = (g.N & 3) == 0;
+    const bool vec_ok = (g.ldc & 3) == 0;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = ncol + j * 16;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
             const int m = mrow + i * 16;
             if (m >= g.M || n >= g.N) continue;
             const v4i a = acc[i][j];
-            const size_t idx = static_cast<size_t>(m) * g.N + n;
+            const size_t idx = static_cast<size_t>(m) * g.ldc + n;
             if constexpr (OUT == kOutI32) {
                 int* o = static_cast<int*>(g.out) + idx;
                 if (vec_ok && n + 3 < g.N) {
@@ -319,7 +323,9 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     MIQ_BARRIER();
     // Waves 4-7 (the second wave on each SIMD) run one barrier behind waves 0-3: while one group
     // issues MFMAs the other does its LDS reads and DMA, so the matrix pipe never waits for loads.
-    if (wm == 1) MIQ_BARRIER();
+    if constexpr (VARIANT != 3) {
+        if (wm == 1) MIQ_BARRIER();
+    }
 
     v4i af[2][4] = {}, af2[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [k-step][fragment]
     auto read_w = [&](v4i (&wf)[2][2], const char* half) {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             last = now;                                               \
         }                                                             \
     } while (0)
-    if constexpr (VARIANT == 2) read_a(af, smem + 0 * kHalf);   // A0(0)
+    if constexpr (VARIANT >= 2) read_a(af, smem + 0 * kHalf);   // A0(0)
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * kBuf;
         char* nxt = smem + ((t + 1) & 1) * kBuf;
@@ -474,17 +480,273 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
             mma(acc[1][0], af2, wf0);
             __builtin_amdgcn_s_setprio(0);
             MIQ_BARRIER();
+        } else if constexpr (VARIANT == 3) {
+            // Variant 2's instruction stream with ONE barrier per phase and wave: waves 0-3 run LOAD, MFMA,
+            // wait, barrier; waves 4-7 run LOAD, wait, barrier, MFMA, so that after every barrier one wave of
+            // a SIMD starts on its MFMAs while the other starts on its loads, and nothing forces the two to
+            // alternate in between.  The waits and distances are variant 2's: a half-tile is read one phase
+            // after the wait that retires it and re-staged two phases after its last read.
+#define MIQ_PHASE3(LOADS, ACC, AF, WF)                \
+            LOADS;                                    \
+            if (wm == 1) {                            \
+                MIQ_WAIT_DMA();                       \
+                MIQ_BARRIER();                        \
+            }                                         \
+            __builtin_amdgcn_s_setprio(1);            \
+            mma(ACC, AF, WF);                         \
+            __builtin_amdgcn_s_setprio(0);            \
+            if (wm == 0) {                            \
+                MIQ_WAIT_DMA();                       \
+                MIQ_BARRIER();                        \
+            }
+            MIQ_PHASE3((read_w(wf0, cur + 2 * kHalf), stage_half(rw, nxt + 3 * kHalf, wbase[1], t + 1)), acc[0][0], af, wf0);
+            MIQ_PHASE3((read_w(wf1, cur + 3 * kHalf), stage_half(ra, nxt + 1 * kHalf, abase[1], t + 1)), acc[0][1], af, wf1);
+            MIQ_PHASE3((read_a(af2, cur + 1 * kHalf), stage_half(ra, cur + 0 * kHalf, abase[0], t + 2)), acc[1][1], af2, wf1);
+            MIQ_PHASE3((read_a(af, nxt + 0 * kHalf), stage_half(rw, cur + 2 * kHalf, wbase[0], t + 2)), acc[1][0], af2, wf0);
+#undef MIQ_PHASE3
         }
     }
     if constexpr ((ABL & 64) != 0) {
         if (g.stamps != nullptr && lane < 20)
             g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 20 + lane] = seg[lane / 5][lane % 5];
     }
-    if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
+    if constexpr (VARIANT != 3) {
+        if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
 
     store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0>(g, acc, m0, n0, wm, wn, lane);
 }
+
+// ---------------------------------------------------------------------------------------
+// 256 x 384 tile: the kernel the interior of a large GEMM runs on.
+//
+// The 256 x 256 kernel above is bound by the rate at which a CU pulls operand bytes L2 -> LDS, not by
+// its MFMAs; a 256 x 384 tile moves (256 + 384) / (256 * 384) = 5/6 of the bytes per multiply-add.
+// Eight waves as 2 (m) x 4 (n); a wave owns 128 x 96 outputs as 2 x 3 blocks of 64 x 32 (192
+// accumulator registers).  A 128-byte K-tile is five 16 KiB sub-tiles in LDS, A0 A1 (activation rows
+// 0-127 / 128-255) and W0 W1 W2 (weight rows 0-127 / 128-255 / 256-383); block (h, q) of a wave reads
+// its 64 rows of A<h> and its 32 rows of W<q>.  Two K-tile buffers: 160 KiB, all of the CU's LDS.
+//
+// A K-tile is four phases of 24 MFMAs, (k-step, h) = (0,0) (0,1) (1,0) (1,1): the six weight
+// fragments of a k-step stay in registers for two phases, the four activation fragments are read per
+// phase (40 operand registers).  A phase is LOAD (fragment reads, LDS-DMA for the NEXT K-tile, a
+// counted vmcnt) | barrier | 24 MFMAs | barrier, and waves 4-7 run one barrier behind waves 0-3, so
+// one wave of every SIMD computes while the other loads.
+//   P1: read W*(k0) A0(k0) | DMA A0 W0 of t+1 | vmcnt(4): A1(t) landed     | MFMA (0, q)
+//   P2: read A1(k0)        | DMA W1 W2 of t+1 |                            | MFMA (1, q)
+//   P3: read W*(k1) A0(k1) | DMA A1 of t+1    |                            | MFMA (0, q)
+//   P4: read A1(k1)        |                  | vmcnt(2): A0 W* of t+1 landed | MFMA (1, q)
+// A sub-tile is read no earlier than one phase after the wait that retires it and re-staged no
+// earlier than two phases after its last read (the MFMAs that consume a read sit before the barrier
+// that ends its phase; with the two wave groups one barrier apart that is the distance at which every
+// wave has consumed its reads / passed its wait).
+//
+// Only tiles that lie wholly inside the matrices come here (M % 256 == 0, N % 384 == 0, K % 128 == 0
+// for the block this launch covers): a lane's buffer offset is then fixed for the whole kernel and
+// the K-tile and row-group advance in the instruction's scalar offset, which leaves the main loop
+// without vector address arithmetic.  K-tiles past the end are requested through a descriptor of
+// zero records (no memory traffic) so that every wave issues the same count of DMA instructions.
+// ---------------------------------------------------------------------------------------
+#ifndef MIQ_NO_DEV_SWITCHES
+template <int OUT, int SCHED = 0>
+__global__ __launch_bounds__(512) void gemm_i8_wide_kernel(GemmArgs g) {
+    constexpr int kSub = 128 * kTileK;   // one sub-tile: 128 rows x 128 B
+    constexpr int kStage = 5 * kSub;     // A0 A1 W0 W1 W2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 384;
+    const uint32_t K = static_cast<uint32_t>(g.K);
+    const int nt = g.K / kTileK;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A, static_cast<uint32_t>(g.M) * K);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, static_cast<uint32_t>(g.N) * K);
+    const __amdgpu_buffer_rsrc_t ra_none = make_rsrc(g.A, 0), rw_none = make_rsrc(g.W, 0);
+
+    // Staging: a wave-instruction (a "piece") moves 8 rows x 128 B; a wave issues two per sub-tile (row
+    // groups `wave` and `wave + 8`, 64 rows apart).  The chunk a lane fetches is fixed by the swizzle.
+    const int srow = wave * 8 + (lane >> 3);
+    const int cbyte = ((lane & 7) ^ ((srow >> 1) & 7)) * kChunk;
+    const uint32_t va = static_cast<uint32_t>(m0 + srow) * K + cbyte;
+    const uint32_t vw = static_cast<uint32_t>(n0 + srow) * K + cbyte;
+    // sub: 0, 1 = A0, A1; 2, 3, 4 = W0, W1, W2.  pieces: bit 0 = rows 0-63 of the sub-tile, bit 1 = rows 64-127.
+    auto stage = [&](char* stg, int sub, int pieces, int kt) {
+        const bool is_w = sub >= 2;
+        const __amdgpu_buffer_rsrc_t rs = is_w ? (kt < nt ? rw : rw_none) : (kt < nt ? ra : ra_none);
+        const uint32_t so = static_cast<uint32_t>(kt) * kTileK + static_cast<uint32_t>(is_w ? sub - 2 : sub) * 128u * K;
+        char* dst = stg + sub * kSub + wave * (8 * kTileK);
+        const uint32_t v = is_w ? vw : va;
+        if (pieces & 1) dma16s(rs, dst, v, so);
+        if (pieces & 2) dma16s(rs, dst + 8 * (8 * kTileK), v, so + 64u * K);
+    };
+
+    v4i acc[2][3][4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][q][i][j] = v4i{0, 0, 0, 0};
+
+    const int lo[2] = {frag_lane_offset(lane, 0), frag_lane_offset(lane, 1)};
+    const int a_frag = wm * 64 * kTileK;   // this wave's rows inside an A sub-tile
+    const int w_frag = wn * 32 * kTileK;   // and inside a W sub-tile
+
+    v4i wf[3][2] = {}, af[4] = {};
+    auto read_w = [&](const char* stg, int ks) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[q][j] = lds_read16(stg + (2 + q) * kSub + w_frag + j * 16 * kTileK + lo[ks]);
+    };
+    auto read_a = [&](const char* stg, int h, int ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = lds_read16(stg + h * kSub + a_frag + i * 16 * kTileK + lo[ks]);
+    };
+    // 24 MFMAs; `mid(u)` runs after the MFMAs of weight fragment pair q = u (u = 0, 1): the place SCHED 3 issues DMA from
+    auto mma = [&](v4i (&c)[3][4][2], auto&& mid) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    c[q][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[q][j], af[i], c[q][i][j], 0, 0, 0);
+            if (q < 2) mid(q);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto none = [](int) {};
+
+#define MIQ_WIDE_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    // Prologue: all of K-tile 0, A1 last (the loop's first wait expects it to be the youngest but for what SCHED 3
+    // stages ahead).
+    stage(smem, 0, 3, 0);
+    stage(smem, 2, 3, 0);
+    stage(smem, 3, 3, 0);
+    stage(smem, 4, 3, 0);
+    stage(smem, 1, 3, 0);
+    if constexpr (SCHED == 3) {
+        stage(smem + kStage, 0, 3, 1);
+        stage(smem + kStage, 2, 1, 1);
+        MIQ_WIDE_WAIT(5);
+    } else {
+        MIQ_WIDE_WAIT(2);   // A0 W0 W1 W2 of tile 0
+    }
+    MIQ_BARRIER();
+    if (wm == 1) MIQ_BARRIER();   // waves 4-7 run one barrier behind
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * kStage;
+        char* oth = smem + ((t + 1) & 1) * kStage;
+        if constexpr (SCHED == 0 || SCHED == 1) {
+            // DMA per phase 4 / 4 / 2 / 0
+            if constexpr (SCHED == 1) { stage(oth, 0, 3, t + 1); stage(oth, 2, 3, t + 1); }
+            read_w(cur, 0);
+            read_a(cur, 0, 0);
+            if constexpr (SCHED == 0) { stage(oth, 0, 3, t + 1); stage(oth, 2, 3, t + 1); }
+            MIQ_WIDE_WAIT(4);   // A1(t)
+            MIQ_BARRIER();
+            mma(acc[0], none);
+            MIQ_BARRIER();
+
+            if constexpr (SCHED == 1) { stage(oth, 3, 3, t + 1); stage(oth, 4, 3, t + 1); }
+            read_a(cur, 1, 0);
+            if constexpr (SCHED == 0) { stage(oth, 3, 3, t + 1); stage(oth, 4, 3, t + 1); }
+            MIQ_BARRIER();
+            mma(acc[1], none);
+            MIQ_BARRIER();
+
+            if constexpr (SCHED == 1) stage(oth, 1, 3, t + 1);
+            read_w(cur, 1);
+            read_a(cur, 0, 1);
+            if constexpr (SCHED == 0) stage(oth, 1, 3, t + 1);
+            MIQ_BARRIER();
+            mma(acc[0], none);
+            MIQ_BARRIER();
+
+            read_a(cur, 1, 1);
+            MIQ_WIDE_WAIT(2);   // A0 W0 W1 W2 of tile t+1
+            MIQ_BARRIER();
+            mma(acc[1], none);
+            MIQ_BARRIER();
+        } else if constexpr (SCHED == 2 || SCHED == 4) {
+            // DMA per phase 3 / 3 / 2 / 2: A0 W0a | W0b W1 | W2 | A1   (SCHED 4: issued before the reads)
+            if constexpr (SCHED == 4) { stage(oth, 0, 3, t + 1); stage(oth, 2, 1, t + 1); }
+            read_w(cur, 0);
+            read_a(cur, 0, 0);
+            if constexpr (SCHED == 2) { stage(oth, 0, 3, t + 1); stage(oth, 2, 1, t + 1); }
+            MIQ_WIDE_WAIT(3);   // A1(t), issued one phase ago
+            MIQ_BARRIER();
+            mma(acc[0], none);
+            MIQ_BARRIER();
+
+            if constexpr (SCHED == 4) { stage(oth, 2, 2, t + 1); stage(oth, 3, 3, t + 1); }
+            read_a(cur, 1, 0);
+            if constexpr (SCHED == 2) { stage(oth, 2, 2, t + 1); stage(oth, 3, 3, t + 1); }
+            MIQ_BARRIER();
+            mma(acc[1], none);
+            MIQ_BARRIER();
+
+            if constexpr (SCHED == 4) stage(oth, 4, 3, t + 1);
+            read_w(cur, 1);
+            read_a(cur, 0, 1);
+            if constexpr (SCHED == 2) stage(oth, 4, 3, t + 1);
+            MIQ_BARRIER();
+            mma(acc[0], none);
+            MIQ_BARRIER();
+
+            if constexpr (SCHED == 4) stage(oth, 1, 3, t + 1);
+            read_a(cur, 1, 1);
+            if constexpr (SCHED == 2) stage(oth, 1, 3, t + 1);
+            MIQ_WIDE_WAIT(2);   // A0 W0 W1 W2 of tile t+1
+            MIQ_BARRIER();
+            mma(acc[1], none);
+            MIQ_BARRIER();
+        } else {
+            // SCHED 3: DMA issued between the MFMAs, 3 / 2 / 2 / 3 per phase: W0b W1 | W2 | A1 of tile t+1, then
+            // A0 W0a of tile t+2 (their buffers were last read in P3 and are consumed by the barrier before P4's MFMAs)
+            read_w(cur, 0);
+            read_a(cur, 0, 0);
+            MIQ_WIDE_WAIT(3);   // A1(t)
+            MIQ_BARRIER();
+            mma(acc[0], [&](int u) { if (u == 0) { stage(oth, 2, 2, t + 1); stage(oth, 3, 1, t + 1); } else stage(oth, 3, 2, t + 1); });
+            MIQ_BARRIER();
+
+            read_a(cur, 1, 0);
+            MIQ_BARRIER();
+            mma(acc[1], [&](int u) { stage(oth, 4, u == 0 ? 1 : 2, t + 1); });
+            MIQ_BARRIER();
+
+            read_w(cur, 1);
+            read_a(cur, 0, 1);
+            MIQ_BARRIER();
+            mma(acc[0], [&](int u) { stage(oth, 1, u == 0 ? 1 : 2, t + 1); });
+            MIQ_BARRIER();
+
+            read_a(cur, 1, 1);
+            MIQ_WIDE_WAIT(2);   // A0 W0 W1 W2 of tile t+1 (all but A1's two)
+            MIQ_BARRIER();
+            mma(acc[1], [&](int u) { if (u == 0) stage(cur, 0, 3, t + 2); else stage(cur, 2, 1, t + 2); });
+            MIQ_BARRIER();
+        }
+    }
+#undef MIQ_WIDE_WAIT
+    if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-record DMAs issued for the tiles past K
+
+    store_tile_256<OUT, true, true, 3>(g, acc, m0, n0, wm, wn, lane);
+}
+#endif   // MIQ_NO_DEV_SWITCHES
 
 // Any K and any alignment: one thread per output element.  Only shapes the MFMA path cannot
 // take (K not a multiple of 16, or misaligned pointers) come here; they are tiny layers.
@@ -497,14 +759,15 @@ __global__ __launch_bounds__(256) void gemm_i8_any_kernel(GemmArgs g) {
         const int8_t* w = g.W + static_cast<int64_t>(n) * g.K;
         int sum = 0;
         for (int k = 0; k < g.K; ++k) sum += static_cast<int>(a[k]) * static_cast<int>(w[k]);
+        const size_t o = static_cast<size_t>(m) * g.ldc + n;
         if constexpr (OUT == kOutI32) {
-            static_cast<int*>(g.out)[idx] = sum;
+            static_cast<int*>(g.out)[o] = sum;
         } else {
             const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
             if constexpr (OUT == kOutF32) {
-                static_cast<float*>(g.out)[idx] = y;
+                static_cast<float*>(g.out)[o] = y;
             } else {
-                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+                static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y);
             }
         }
     }
@@ -518,14 +781,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const int* __restric
         int sum = 0;
         for (int s = 0; s < splits; ++s) sum += slabs[s * total + idx];
         const int n = static_cast<int>(idx % g.N);
+        const size_t o = static_cast<size_t>(idx / g.N) * g.ldc + n;
         if constexpr (OUT == kOutI32) {
-            static_cast<int*>(g.out)[idx] = sum;
+            static_cast<int*>(g.out)[o] = sum;
         } else {
             const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
             if constexpr (OUT == kOutF32) {
-                static_cast<float*>(g.out)[idx] = y;
+                static_cast<float*>(g.out)[o] = y;
             } else {
-                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
+                static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y);
             }
         }
     }
@@ -628,7 +892,7 @@ __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
         int sum = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) sum += red[w * MT * WN * 256 + src];
-        const size_t idx = static_cast<size_t>(m) * g.N + n;
+        const size_t idx = static_cast<size_t>(m) * g.ldc + n;
         if constexpr (OUT == kOutI32) {
             static_cast<int*>(g.out)[idx] = sum;
         } else {
@@ -745,33 +1009,24 @@ int launch_tile(GemmArgs g, hipStream_t st, int splits = 1, int kt_per_split = 0
     return check_launch("gemm_i8_kernel");
 }
 
+// The 256 x 256 kernel of a product build is gemm_i8_256_kernel<OUT, 2, 0> and nothing else.  The other
+// instantiations (an earlier schedule, and timing-only builds that leave out DMA, LDS reads, MFMAs or stores and
+// therefore return WRONG results) exist only in the developer library, which is built without
+// MIQ_NO_DEV_SWITCHES and loaded by tools/ alone.
 template <int OUT>
-int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
-    if (!mfma_ok) {
-        const int64_t total = static_cast<int64_t>(g.M) * g.N;
-        const int grid = static_cast<int>(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
-        gemm_i8_any_kernel<OUT><<<grid, 256, 0, st>>>(g);
-        return check_launch("gemm_i8_any_kernel");
-    }
-    // Tile choice: the 256x256 tile (8 waves, 128 KiB LDS) once both dimensions can fill the
-    // chip with it; smaller tiles keep more workgroups in flight for thin problems.
-    const GemmPlan plan = plan_gemm(g.M, g.N, g.K);
-    if (plan.bm == 0) return launch_skinny<1, OUT>(g, st);
-    if (plan.bm == 256) {
-        const char* simple = dev_switch("MIQ_GEMM_SIMPLE");   // developer A/B switch
-        if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
-        g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
-        g.tiles_n = static_cast<int>(ceil_div(g.N, 256));
-        constexpr int kLds = 2 * 4 * 128 * kTileK;
-        const char* var = dev_switch("MIQ_GEMM_VARIANT");     // developer A/B switch
-        auto kern = (var && var[0] == '0') ? gemm_i8_256_kernel<OUT, 0> : gemm_i8_256_kernel<OUT, 2>;
-        const char* abl = dev_switch("MIQ_GEMM_ABL");
-        if (abl && abl[0] == 'n') kern = gemm_i8_256_kernel<OUT, 2, 256>;   // plain (cached) epilogue stores
-        if (abl && abl[0] == 'h') kern = gemm_i8_256_kernel<OUT, 2, 512>;   // bf16: 8-byte stores, fragments unpaired
-        if (abl && abl[0] == 'H') kern = gemm_i8_256_kernel<OUT, 2, 512 + 256>;
-        if (abl && OUT == kOutF32) {
+auto pick_256_kernel(GemmArgs& g) -> void (*)(GemmArgs) {
+    void (*kern)(GemmArgs) = gemm_i8_256_kernel<OUT, 2>;
+#ifndef MIQ_NO_DEV_SWITCHES
+    const char* var = dev_switch("MIQ_GEMM_VARIANT");
+    if (var && var[0] == '0') kern = gemm_i8_256_kernel<OUT, 0>;
+    if (var && var[0] == '3') kern = gemm_i8_256_kernel<OUT, 3>;
+    const char* abl = dev_switch("MIQ_GEMM_ABL");
+    if (abl && abl[0] == 'n') kern = gemm_i8_256_kernel<OUT, 2, 256>;   // plain (cached) epilogue stores
+    if (abl && abl[0] == 'h') kern = gemm_i8_256_kernel<OUT, 2, 512>;   // bf16: 8-byte stores, fragments unpaired
+    if (abl && abl[0] == 'H') kern = gemm_i8_256_kernel<OUT, 2, 512 + 256>;
+    if constexpr (OUT == kOutF32) {
+        if (abl) {
             if (abl[0] == '1') kern = gemm_i8_256_kernel<OUT, 0, 1>;
-            if (abl[0] == '6') kern = gemm_i8_256_kernel<OUT, 0, 8>;
             if (abl[0] == '7') kern = gemm_i8_256_kernel<OUT, 0, 16>;
             if (abl[0] == '8') kern = gemm_i8_256_kernel<OUT, 0, 16 + 2>;
             if (abl[0] == '9') kern = gemm_i8_256_kernel<OUT, 0, 16 + 2 + 8>;
@@ -788,6 +1043,22 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
             if (abl[0] == '5') kern = gemm_i8_256_kernel<OUT, 0, 8 + 2>;
             if (abl[0] == '6') kern = gemm_i8_256_kernel<OUT, 0, 8>;
         }
+    }
+#endif
+    return kern;
+}
+
+// One sub-problem on the kernel its plan names.
+template <int OUT>
+int launch(GemmArgs g, const GemmPlan& plan, int* slabs, hipStream_t st) {
+    if (plan.bm == 0) return launch_skinny<1, OUT>(g, st);
+    if (plan.bm == 256) {
+        const char* simple = dev_switch("MIQ_GEMM_SIMPLE");   // developer A/B switch
+        if (simple && simple[0] == '1') return launch_tile<256, 256, 2, 4, OUT>(g, st);
+        g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
+        g.tiles_n = static_cast<int>(ceil_div(g.N, 256));
+        constexpr int kLds = 2 * 4 * 128 * kTileK;
+        auto kern = pick_256_kernel<OUT>(g);
         if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
         kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
         return check_launch("gemm_i8_256_kernel");
@@ -837,105 +1108,220 @@ int launch(GemmArgs g, bool mfma_ok, int* slabs, hipStream_t st) {
     return launch_tile<16, 64, 1, 4, OUT>(g, st, plan.splits, plan.kt_per_split, slabs);
 }
 
-}  // namespace
-
-namespace {
-// Workspace = [re-laid [N,K] weight, only for MIQ_W_KN][split-K int32 slabs, only for thin problems].
-size_t transposed_bytes(int w_layout, int64_t N, int64_t K) {
-    return w_layout == MIQ_W_KN ? static_cast<size_t>(miq::round_up(N * K, 256)) : 0;
+template <int OUT>
+int launch_any(const GemmArgs& g, hipStream_t st) {
+    const int64_t total = static_cast<int64_t>(g.M) * g.N;
+    const int grid = static_cast<int>(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+    gemm_i8_any_kernel<OUT><<<grid, 256, 0, st>>>(g);
+    return check_launch("gemm_i8_any_kernel");
 }
+
+// The 256 x 384 kernel on a block of whole tiles (g.M % 256 == 0, g.N % 384 == 0, g.K % 128 == 0).
+template <int OUT>
+int launch_wide(GemmArgs g, hipStream_t st) {
+#ifdef MIQ_NO_DEV_SWITCHES
+    (void)g; (void)st;
+    return fail(MIQ_EINVAL, "the 256 x 384 kernel exists only in the developer library");
+#else
+    g.tiles_m = g.M / 256;
+    g.tiles_n = g.N / 384;
+    constexpr int kLds = 2 * 5 * 128 * kTileK;   // 160 KiB: the whole LDS of a CU
+    void (*kern)(GemmArgs) = gemm_i8_wide_kernel<OUT>;
+    const char* sc = dev_switch("MIQ_GEMM_WIDE_SCHED");   // developer A/B switch: where the wide kernel issues its DMA
+    if (sc && sc[0] == '1') kern = gemm_i8_wide_kernel<OUT, 1>;
+    if (sc && sc[0] == '2') kern = gemm_i8_wide_kernel<OUT, 2>;
+    if (sc && sc[0] == '3') kern = gemm_i8_wide_kernel<OUT, 3>;
+    if (sc && sc[0] == '4') kern = gemm_i8_wide_kernel<OUT, 4>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    kern<<<g.tiles_m * g.tiles_n, 512, kLds, st>>>(g);
+    return check_launch("gemm_i8_wide_kernel");
+#endif
+}
+
 // A tile count a little over whole rounds of the 256 CUs costs the 256 x 256 kernel a whole extra round (288 tiles
 // take as long as 384: 169 against 104 us for 256).  Such problems are cut along M: the tile rows that make whole
 // rounds run on the 256 x 256 kernel, the few remaining rows as a second, small problem on the thin-tile kernels
 // (2304 x 8192 x 8192: 169 -> 136 us).  Returns the rows of the first part, M when the problem stays whole.
-int64_t rows_in_whole_rounds(int64_t M, int64_t N, int64_t K) {
-    if (plan_gemm(M, N, K).bm != 256) return M;
-    const char* sw = miq::dev_switch("MIQ_GEMM_ROWSPLIT");   // developer A/B switch: 0 = never cut
+int64_t rows_in_whole_rounds(int64_t M, int64_t N, const GemmPlan& whole) {
+    if (whole.bm != 256) return M;
+    const char* sw = dev_switch("MIQ_GEMM_ROWSPLIT");   // developer A/B switch: 0 = never cut
     if (sw && sw[0] == '0') return M;
-    const int64_t tn = miq::ceil_div(N, 256), tm = miq::ceil_div(M, 256), tiles = tm * tn;
+    const int64_t tn = ceil_div(N, 256), tm = ceil_div(M, 256), tiles = tm * tn;
     if (tiles <= 256 || tiles % 256 == 0) return M;
     const int64_t tm_main = (tiles / 256) * 256 / tn;   // tile rows inside the whole rounds
     if (tm_main < 1 || tm_main >= tm) return M;
-    const int64_t main_tiles = tm_main * tn, tail_tiles = miq::ceil_div(M - tm_main * 256, 256) * tn;
+    const int64_t main_tiles = tm_main * tn, tail_tiles = ceil_div(M - tm_main * 256, 256) * tn;
     if (main_tiles % 256 != 0 && main_tiles % 256 < 200) return M;   // the rounds kept must be (nearly) full
     if (tail_tiles > 96) return M;                                   // ... and the rest small against a round
     return tm_main * 256;
 }
-size_t slab_bytes(int64_t M, int64_t N, int64_t K) {
-    if (K % 16 != 0) return 0;
-    const int64_t m_main = rows_in_whole_rounds(M, N, K);
-    if (m_main < M) M -= m_main;   // only the second part can need slabs
-    const GemmPlan p = plan_gemm(M, N, K);
-    return p.splits > 1 ? static_cast<size_t>(miq::round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
+
+// How one call is cut into launches.  Made once per call (the workspace query makes it again for the same
+// sizes): up to three blocks of the output, each with the kernel plan it runs on.
+//   wide:  rows [0, M) x channels [0, wide_n) on the 256 x 384 kernel (wide_n = 0: none)
+//   head:  rows [0, head_m) x channels [wide_n, N) on `head`
+//   tail:  rows [head_m, M) x channels [wide_n, N) on `tail` (head_m = M: none)
+struct Schedule {
+    int64_t wide_n, head_m;
+    GemmPlan head, tail;
+    size_t slab_bytes;   // int32 split-K slabs of the one block that needs them (the blocks run one after another)
+};
+
+// Channels for the 256 x 384 kernel: none in the product library.  Measured on MI355X (tools/gemm_wide_ab.py,
+// profiles/r2_gemm_wide.txt) the wide tile moves 17 % fewer bytes L2 -> LDS and issues 22 % fewer LDS reads per
+// multiply-add, holds the matrix pipes busy for the same share of cycles at the same clock, and ends within 1 % of
+// the 256 x 256 kernel in time: the chip is power-limited on random int8 operands, not limited by that stream.  The
+// kernel stays in the developer library as the measured alternative (MIQ_GEMM_WIDE = count of 384-channel tile
+// columns to give it).
+int64_t wide_columns(int64_t M, int64_t N, int64_t K) {
+#ifdef MIQ_NO_DEV_SWITCHES
+    (void)M; (void)N; (void)K;
+    return 0;
+#else
+    const char* sw = dev_switch("MIQ_GEMM_WIDE");
+    if (!sw || sw[0] == '0') return 0;
+    if (M % 256 != 0 || K % 128 != 0 || M < 256 || N < 384) return 0;
+    const int64_t forced = atoll(sw);
+    return forced * 384 <= N ? forced * 384 : 0;
+#endif
 }
-}  // namespace
 
-extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return transposed_bytes(w_layout, N, K) + slab_bytes(M, N, K);
+Schedule make_schedule(int64_t M, int64_t N, int64_t K, bool mfma_ok) {
+    Schedule s{};
+    s.head_m = M;
+    if (!mfma_ok) return s;
+    s.wide_n = wide_columns(M, N, K);
+    const int64_t n_rest = N - s.wide_n;
+    if (n_rest == 0) return s;
+    s.head = plan_gemm(M, n_rest, K);
+    s.head_m = rows_in_whole_rounds(M, n_rest, s.head);
+    auto slabs = [&](const GemmPlan& p, int64_t rows) {
+        return p.splits > 1 ? static_cast<size_t>(round_up(static_cast<int64_t>(p.splits) * rows * n_rest * 4, 256)) : size_t{0};
+    };
+    if (s.head_m < M) {
+        s.head = plan_gemm(s.head_m, n_rest, K);   // whole rounds of 256 x 256 tiles: never split
+        s.tail = plan_gemm(M - s.head_m, n_rest, K);
+        s.slab_bytes = slabs(s.tail, M - s.head_m);
+    } else {
+        s.slab_bytes = slabs(s.head, M);
+    }
+    return s;
 }
 
+// Workspace = [re-laid [N,K] weight, only for MIQ_W_KN][split-K int32 slabs, only for thin problems].
+size_t transposed_bytes(int w_layout, int64_t N, int64_t K) {
+    return w_layout == MIQ_W_KN ? static_cast<size_t>(round_up(N * K, 256)) : 0;
+}
 
-extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
-                           const float* bias, const float* alpha, float beta, void* out, int out_dtype,
-                           void* workspace, size_t workspace_bytes, void* stream) {
-    MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "miq_gemm_i8: negative size (M=%lld N=%lld K=%lld)",
-                (long long)M, (long long)N, (long long)K);
-    MIQ_REQUIRE(w_layout == MIQ_W_NK || w_layout == MIQ_W_KN, MIQ_EINVAL, "miq_gemm_i8: unknown w_layout %d", w_layout);
+bool mfma_path_ok(const int8_t* A, const int8_t* W, int w_layout, int64_t N, int64_t K, const void* out) {
+    // 16-byte vector stores in the epilogue (four fp32 / int32, or eight bf16 when N % 8 == 0) need 16-byte
+    // aligned output rows whenever N % 4 == 0.  A [K,N] weight is re-laid into the 256-byte aligned workspace.
+    const bool out_vec_ok = (N % 4 != 0) || aligned(out, 16);
+    return K > 0 && K % 16 == 0 && aligned(A, 16) && (w_layout == MIQ_W_KN || aligned(W, 16)) && out_vec_ok;
+}
+
+int validate(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K, const float* bias,
+             const float* alpha, const void* out, int out_dtype, const char* who) {
+    MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "%s: negative size (M=%lld N=%lld K=%lld)", who, (long long)M,
+                (long long)N, (long long)K);
+    MIQ_REQUIRE(w_layout == MIQ_W_NK || w_layout == MIQ_W_KN, MIQ_EINVAL, "%s: unknown w_layout %d", who, w_layout);
     MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32, MIQ_EINVAL,
-                "miq_gemm_i8: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", out_dtype);
+                "%s: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", who, out_dtype);
     if (M == 0 || N == 0) return MIQ_OK;
-    MIQ_REQUIRE(out, MIQ_EINVAL, "miq_gemm_i8: null output");
-    MIQ_REQUIRE(K == 0 || (A && W), MIQ_EINVAL, "miq_gemm_i8: null operand");
-    MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "miq_gemm_i8: alpha is required for a dequantised output");
+    MIQ_REQUIRE(out, MIQ_EINVAL, "%s: null output", who);
+    MIQ_REQUIRE(K == 0 || (A && W), MIQ_EINVAL, "%s: null operand", who);
+    MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "%s: alpha is required for a dequantised output", who);
     MIQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && M * K < (1ll << 31) && N * K < (1ll << 31),
-                MIQ_ERANGE, "miq_gemm_i8: operands are indexed with 31-bit byte offsets (M*K and N*K < 2^31)");
+                MIQ_ERANGE, "%s: operands are indexed with 31-bit byte offsets (M*K and N*K < 2^31)", who);
     const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
-    MIQ_REQUIRE(miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
-                "miq_gemm_i8: out/alpha/bias not aligned to their element size");
-    hipStream_t st = miq::as_stream(stream);
+    MIQ_REQUIRE(aligned(out, esz) && aligned(alpha, 4) && aligned(bias, 4), MIQ_EALIGN,
+                "%s: out/alpha/bias not aligned to their element size", who);
+    return MIQ_OK;
+}
 
+// Everything after validation and the workspace check: the optional weight re-layout and the launches of the
+// schedule.  `workspace` holds transposed_bytes() + sched.slab_bytes bytes.
+int run_schedule(const Schedule& sched, const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                 const float* bias, const float* alpha, float beta, void* out, int out_dtype, bool mfma_ok,
+                 void* workspace, void* stream) {
+    hipStream_t st = as_stream(stream);
+    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
     int* slabs = nullptr;
     if (K > 0) {
-        const size_t need = miq_gemm_i8_workspace(w_layout, M, N, K);
-        if (need) {
-            MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
-                        "miq_gemm_i8: this call needs %zu bytes of workspace (got %zu): see miq_gemm_i8_workspace", need,
-                        workspace_bytes);
-            MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
-        }
         if (w_layout == MIQ_W_KN) {
             int rc = miq_transpose_i8(W, K, N, static_cast<int8_t*>(workspace), stream);
             if (rc != MIQ_OK) return rc;
             W = static_cast<const int8_t*>(workspace);
         }
-        if (slab_bytes(M, N, K)) slabs = reinterpret_cast<int*>(static_cast<char*>(workspace) + transposed_bytes(w_layout, N, K));
+        if (sched.slab_bytes) slabs = reinterpret_cast<int*>(static_cast<char*>(workspace) + transposed_bytes(w_layout, N, K));
     }
-
-    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0, 0, 0, nullptr};
-    // 16-byte vector stores in the epilogue need out rows 16-byte aligned when N % 4 == 0.
-    const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
-    const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(A, 16) && miq::aligned(W, 16) && out_vec_ok &&
-                         (out_dtype == MIQ_I32 || (miq::aligned(alpha, 4) && miq::aligned(bias, 4)));
-    auto run = [&](const GemmArgs& part, int* part_slabs) {
+    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K),
+               static_cast<int>(N), 0, 0, 0, nullptr};
+    if (!mfma_ok) {
         switch (out_dtype) {
-            case MIQ_F32:
-                return launch<kOutF32>(part, mfma_ok, part_slabs, st);
-            case MIQ_BF16:
-                return launch<kOutBF16>(part, mfma_ok, part_slabs, st);
-            default:
-                return launch<kOutI32>(part, mfma_ok, part_slabs, st);
+            case MIQ_F32: return launch_any<kOutF32>(g, st);
+            case MIQ_BF16: return launch_any<kOutBF16>(g, st);
+            default: return launch_any<kOutI32>(g, st);
+        }
+    }
+    auto run = [&](const GemmArgs& part, const GemmPlan& plan, int* part_slabs) {
+        switch (out_dtype) {
+            case MIQ_F32: return launch<kOutF32>(part, plan, part_slabs, st);
+            case MIQ_BF16: return launch<kOutBF16>(part, plan, part_slabs, st);
+            default: return launch<kOutI32>(part, plan, part_slabs, st);
         }
     };
-    const int64_t m_main = mfma_ok ? rows_in_whole_rounds(M, N, K) : M;
-    if (m_main < M) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
-        GemmArgs head = g, tail = g;
-        head.M = static_cast<int>(m_main);
-        if (int rc = run(head, nullptr)) return rc;
-        tail.A = A + m_main * K;
-        tail.out = static_cast<char*>(out) + static_cast<size_t>(m_main) * N * esz;
-        tail.M = static_cast<int>(M - m_main);
-        return run(tail, slabs);
+    if (sched.wide_n) {
+        GemmArgs wide = g;
+        wide.N = static_cast<int>(sched.wide_n);
+        int rc;
+        switch (out_dtype) {
+            case MIQ_F32: rc = launch_wide<kOutF32>(wide, st); break;
+            case MIQ_BF16: rc = launch_wide<kOutBF16>(wide, st); break;
+            default: rc = launch_wide<kOutI32>(wide, st); break;
+        }
+        if (rc != MIQ_OK || sched.wide_n == N) return rc;
+        // the remaining channels: a column block of the same output
+        g.W = W + sched.wide_n * K;
+        if (bias) g.bias = bias + sched.wide_n;
+        if (alpha) g.alpha = alpha + sched.wide_n;
+        g.out = static_cast<char*>(out) + static_cast<size_t>(sched.wide_n) * esz;
+        g.N = static_cast<int>(N - sched.wide_n);
     }
-    return run(g, slabs);
+    if (sched.head_m < M) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
+        GemmArgs head = g, tail = g;
+        head.M = static_cast<int>(sched.head_m);
+        if (int rc = run(head, sched.head, nullptr)) return rc;
+        tail.A = A + sched.head_m * K;
+        tail.out = static_cast<char*>(g.out) + static_cast<size_t>(sched.head_m) * N * esz;
+        tail.M = static_cast<int>(M - sched.head_m);
+        return run(tail, sched.tail, slabs);
+    }
+    return run(g, sched.head, slabs);
+}
+
+}  // namespace
+
+extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // (alignment of the caller's pointers is unknown here: a problem that ends on the one-thread-per-output
+    // kernel needs no slabs, so this is an upper bound for it)
+    return transposed_bytes(w_layout, N, K) + make_schedule(M, N, K, K % 16 == 0).slab_bytes;
+}
+
+extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                           const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = validate(A, W, w_layout, M, N, K, bias, alpha, out, out_dtype, "miq_gemm_i8")) return rc;
+    if (M == 0 || N == 0) return MIQ_OK;
+    const bool mfma_ok = mfma_path_ok(A, W, w_layout, N, K, out);
+    const Schedule sched = make_schedule(M, N, K, mfma_ok);
+    const size_t need = K > 0 ? transposed_bytes(w_layout, N, K) + sched.slab_bytes : 0;
+    if (need) {
+        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                    "miq_gemm_i8: this call needs %zu bytes of workspace (got %zu): see miq_gemm_i8_workspace", need,
+                    workspace_bytes);
+        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
+    }
+    return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, mfma_ok, workspace, stream);
 }

@@ -49,6 +49,7 @@ struct W8fArgs {
     // Lp elements (L = KW * Cp of them real) starting row_bytes apart in the padded channels-last planes.
     int HoWo, Wo, cstride, Lp, L;
     uint32_t row_bytes, pix_bytes, img_bytes, lp_magic;
+    int ldc = 0;        // elements between two output rows (GEMM kernels; = N)
 };
 
 __device__ __forceinline__ float bf16_round(float x) { return static_cast<float>(static_cast<__bf16>(x)); }
@@ -1026,7 +1027,9 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
     hipStream_t st = miq::as_stream(stream);
 
     W8fArgs g{x, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), 0u, 0, 0, 0};
-    const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 4 * esz);
+    g.ldc = static_cast<int>(N);
+    // The epilogues store 16-byte vectors (four fp32, or eight bf16 when N % 8 == 0) wherever N % 4 == 0.
+    const bool out_vec_ok = (N % 4 != 0) || miq::aligned(out, 16);
     const bool mfma_ok = K > 0 && K % 16 == 0 && miq::aligned(x, 16) && miq::aligned(W, 16) && out_vec_ok;
     if (!mfma_ok) {
         if (out_dtype == MIQ_F32) {

@@ -12,6 +12,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (the developer build of the library: these switches exist only there)
 from quantization_amd import _native as N  # noqa: E402
 
 B, C, H, Co = (int(v) for v in sys.argv[1:5])

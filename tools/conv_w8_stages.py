@@ -6,6 +6,8 @@ choice): whole calls, median of 3 interleaved rounds, bf16 then fp32 activations
     python tools/conv_w8_stages.py [variants, default 0abcde] [index of the first layer of the list]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (the developer build of the library: these switches exist only there)
 from quantization_amd import _native as N
 def timed(fn, iters=10):
     for _ in range(2): fn()

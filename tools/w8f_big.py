@@ -8,6 +8,8 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (the developer build of the library: these switches exist only there)
 from quantization_amd import _native as N  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3

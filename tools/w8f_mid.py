@@ -1,5 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (the developer build of the library: these switches exist only there)
 from quantization_amd import _native as N
 def timed(fn, iters=30):
     for _ in range(3): fn()
