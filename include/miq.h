@@ -123,6 +123,20 @@ int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64
                 const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* miq_gemm_i8 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and
+ * results as miq_gemm_i8, without the workspace: the scratch a call may need (the re-laid [N,K] copy of a
+ * MIQ_W_KN weight, the int32 slabs of a split-K run) lives in a buffer of
+ * miq_gemm_i8_noalloc_max_workspace() bytes (32 MiB) that is part of the library's code object on every GPU
+ * it runs on.  A call whose miq_gemm_i8_workspace() exceeds that returns MIQ_EWORKSPACE and launches
+ * nothing.  The call allocates and frees nothing and does not synchronise.  Every call on a GPU shares that
+ * GPU's buffer: calls that overlap in time on one GPU (different streams, different host threads) race;
+ * calls on one stream are ordered and safe. */
+size_t miq_gemm_i8_noalloc_max_workspace(void);
+int miq_gemm_i8_noalloc(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                        const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                        void* stream);
+
 /* Weight-only Linear on floating-point activations:
  *       out[m,n] = (sum_k x[m,k] * float(W[n,k]) + bias[n]) * alpha[n] + beta
  *

@@ -37,6 +37,8 @@ SYMBOLS = {
     "miq_epilogue_channels_f32": (_int, [_p, _p, _p, ctypes.c_float, _i64, _i64, _i64, _p, _p]),
     "miq_gemm_i8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_gemm_i8_noalloc_max_workspace": (_size, []),
+    "miq_gemm_i8_noalloc": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p]),
     "miq_gemm_w8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_w8": (_int, [_p, _int, _p, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_conv2d_w8_workspace": (_size, [_int] + [_i64] * 9),

@@ -10,8 +10,17 @@
 //
 // Replaces linear_w8a8_kernel (cuda_kernels/linear_int8/linear_w8a8_kernel.cu:5-22) and the
 // dequantisation the reference's Python applies after its matmul (see include/miq.h).
+#include <mutex>
+
 #include "miq_common.h"
 #include "miq_gemm_core.h"
+
+// Scratch of the allocation-free entry point miq_gemm_i8_noalloc: one array per GPU, part of the loaded code
+// object, held until the process ends.  Host code never passes the array's name to a kernel or a memset (on the
+// host the name is a stand-in, not a device address): scratch_for_current_device() asks the runtime for the
+// address on the current device once and hands that pointer on.
+constexpr size_t kScratchBytes = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 namespace {
 
@@ -1213,6 +1222,28 @@ size_t transposed_bytes(int w_layout, int64_t N, int64_t K) {
     return w_layout == MIQ_W_KN ? static_cast<size_t>(round_up(N * K, 256)) : 0;
 }
 
+// The address of `scratch` (top of this file) on the current device, asked of the runtime once per device.
+
+int scratch_for_current_device(void** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static void* ptrs[kMaxDevices] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(MIQ_ELAUNCH, "miq_gemm_i8_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(MIQ_ERANGE, "miq_gemm_i8_noalloc: device index %d is beyond %d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(MIQ_ELAUNCH, "miq_gemm_i8_noalloc: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+        ptrs[dev] = p;
+    }
+    *out = ptrs[dev];
+    return MIQ_OK;
+}
+
 bool mfma_path_ok(const int8_t* A, const int8_t* W, int w_layout, int64_t N, int64_t K, const void* out) {
     // 16-byte vector stores in the epilogue (four fp32 / int32, or eight bf16 when N % 8 == 0) need 16-byte
     // aligned output rows whenever N % 4 == 0.  A [K,N] weight is re-laid into the 256-byte aligned workspace.
@@ -1324,4 +1355,24 @@ extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64
         MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
     }
     return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, mfma_ok, workspace, stream);
+}
+
+extern "C" size_t miq_gemm_i8_noalloc_max_workspace(void) { return kScratchBytes; }
+
+extern "C" int miq_gemm_i8_noalloc(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                                   const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                                   void* stream) {
+    if (int rc = validate(A, W, w_layout, M, N, K, bias, alpha, out, out_dtype, "miq_gemm_i8_noalloc")) return rc;
+    if (M == 0 || N == 0) return MIQ_OK;
+    const bool mfma_ok = mfma_path_ok(A, W, w_layout, N, K, out);
+    const Schedule sched = make_schedule(M, N, K, mfma_ok);
+    const size_t need = K > 0 ? transposed_bytes(w_layout, N, K) + sched.slab_bytes : 0;
+    MIQ_REQUIRE(need <= kScratchBytes, MIQ_EWORKSPACE,
+                "miq_gemm_i8_noalloc: this call needs %zu bytes of scratch, the built-in buffer holds %zu: use miq_gemm_i8 "
+                "with a caller workspace", need, kScratchBytes);
+    void* ws = nullptr;
+    if (need) {
+        if (int rc = scratch_for_current_device(&ws)) return rc;
+    }
+    return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, mfma_ok, ws, stream);
 }

@@ -68,6 +68,12 @@ def test_argument_validation_needs_no_device():
         lib.miq_conv2d_w8_workspace(0, 4, 64, 28, 28, 128, 1, 1, 1, 0)
     # ... but not with padding or a larger filter
     assert lib.miq_conv2d_i8_workspace(2, 64, 56, 56, 128, 1, 1, 2, 1) == 2 * 58 * 58 * 64 + 128 * 64
+    # the allocation-free variant refuses, before any device call, what its built-in 32 MiB do not hold
+    assert lib.miq_gemm_i8_noalloc_max_workspace() == 32 << 20
+    assert lib.miq_gemm_i8_noalloc(ctypes.c_void_p(64), ctypes.c_void_p(64), 1, 16, 8192, 8192, null, ctypes.c_void_p(64),
+                                   0.0, ctypes.c_void_p(64), 0, null) == -3
+    assert b"scratch" in lib.miq_last_error()
+    assert lib.miq_gemm_i8_noalloc(null, null, 0, 0, 8, 16, null, null, 0.0, null, 3, null) == 0
     # zero-sized problems succeed without touching a device
     assert lib.miq_gemm_i8(null, null, 0, 0, 8, 16, null, null, 0.0, null, 3, null, 0, null) == 0
     assert lib.miq_quantize_rows_sym_i8(null, 0, 0, 16, null, null, null, null, null) == 0
