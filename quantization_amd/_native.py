@@ -55,20 +55,25 @@ SYMBOLS = {
 _lib = None
 
 
+def load(path):
+    """A library built from this package's sources, with the argument types of include/miq.h set."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m quantization_amd.build` "
+            "(the quantization hot path has no CPU fallback)")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def lib():
     """The loaded library; raises RuntimeError if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -m quantization_amd.build` "
-                "(the quantization hot path has no CPU fallback)")
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
 
 

@@ -79,6 +79,19 @@ def test_argument_validation_needs_no_device():
     assert lib.miq_quantize_rows_sym_i8(null, 0, 0, 16, null, null, null, null, null) == 0
 
 
+def test_product_library_has_no_developer_kernels():
+    """libmiq.so holds one schedule of the 256 x 256 GEMM kernel per output type, none of the timing-only builds
+    (which return wrong results), no 256 x 384 kernel, and never reads the environment."""
+    import subprocess
+    from quantization_amd import _native
+    syms = subprocess.run(["nm", "-C", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    stubs = sorted(set(re.findall(r"__device_stub__gemm_i8_256_kernel<(\d+), (\d+), (\d+)>", syms)))
+    assert stubs == [("0", "2", "0"), ("2", "2", "0"), ("3", "2", "0")], stubs
+    assert "gemm_i8_wide_kernel" not in syms
+    dyn = subprocess.run(["nm", "-D", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn, "the product library must not read developer switches"
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product raises instead of computing anything on the host."""
     if torch.cuda.is_available():

@@ -441,9 +441,10 @@ def test_pool_rejects_bad_arguments():
 @pytest.mark.parametrize("M,Nn,K", [(2304, 8192, 272), (2100, 8192, 64), (4352, 8192, 128), (1280, 14336, 144),
                                     (2304, 8190, 96)])
 @pytest.mark.parametrize("od", [torch.int32, torch.float32, torch.bfloat16])
-def test_gemm_whole_rounds_plus_tail(N, M, Nn, K, od, monkeypatch):
+def test_gemm_whole_rounds_plus_tail(N, M, Nn, K, od):
     """Tile counts a little over a multiple of the 256 CUs run as whole rounds of 256 x 256 tiles plus a second
-    launch for the remaining rows: the result must equal the uncut run bit for bit, and the exact product."""
+    launch for the remaining rows: every element must equal the exact product (int32) and the oracle's epilogue
+    of it (fp32 bit for bit; bf16 = that value rounded once)."""
     g = torch.Generator(device="cuda").manual_seed(M + K)
     a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
     w = torch.randint(-128, 128, (Nn, K), generator=g, dtype=torch.int32, device="cuda").to(torch.int8)
@@ -451,9 +452,48 @@ def test_gemm_whole_rounds_plus_tail(N, M, Nn, K, od, monkeypatch):
     bias = torch.randn(Nn, generator=g, device="cuda")
     kw = {} if od == torch.int32 else {"alpha": alpha, "bias": bias}
     y = N.gemm_i8(a, w, out_dtype=od, **kw)
-    monkeypatch.setenv("MIQ_GEMM_ROWSPLIT", "0")
-    y0 = N.gemm_i8(a, w, out_dtype=od, **kw)
-    assert torch.equal(y, y0)
+    exact = (a.double() @ w.double().t()).to(torch.int32)      # |sum| < 2^53: exact
     if od == torch.int32:
-        ref = (a.double() @ w.double().t()).to(torch.int32)      # |sum| < 2^53: exact
-        assert torch.equal(y, ref)
+        assert torch.equal(y, exact)
+    else:
+        ref = OC.epilogue_f32(exact.cpu().numpy(), bias.cpu().numpy(), alpha.cpu().numpy(), 0.0)
+        if od == torch.bfloat16:
+            ref = O.round_f32_to_bf16(ref)
+        np.testing.assert_array_equal(y.float().cpu().numpy(), ref)
+
+
+def test_developer_switches_do_not_reach_the_product(N, monkeypatch):
+    """The environment variables of the developer library (a timing-only GEMM build that skips its DMA, a forced
+    tile, the wide tile) leave the product's results bit-equal."""
+    a, w = rand_i8((512, 512), 5).cuda(), rand_i8((8192, 512), 6).cuda()   # 64 tiles of 256 x 256 ... the big-tile kernel
+    a2, w2 = rand_i8((2048, 256), 7).cuda(), rand_i8((8192, 256), 8).cuda()
+    ref, ref2 = N.gemm_i8(a, w, out_dtype=torch.int32), N.gemm_i8(a2, w2, out_dtype=torch.int32)
+    exact = (a2.double() @ w2.double().T).to(torch.int32)
+    assert torch.equal(ref2, exact)
+    for name, val in (("MIQ_GEMM_ABL", "1"), ("MIQ_GEMM_ABL", "3"), ("MIQ_GEMM_VARIANT", "0"), ("MIQ_GEMM_TILE", "g"),
+                      ("MIQ_GEMM_WIDE", "2"), ("MIQ_GEMM_PLAN256", "0")):
+        monkeypatch.setenv(name, val)
+        assert torch.equal(N.gemm_i8(a, w, out_dtype=torch.int32), ref), name
+        assert torch.equal(N.gemm_i8(a2, w2, out_dtype=torch.int32), ref2), name
+        monkeypatch.delenv(name)
+
+
+@pytest.mark.parametrize("sched", ["0", "1", "2", "3", "4"])
+def test_wide_tile_kernel_of_the_developer_library(N, sched, monkeypatch):
+    """The 256 x 384 kernel (kept in the developer library as the measured alternative to the 256 x 256 tile):
+    a column block of whole wide tiles plus the remaining channels on the ordinary kernels, every DMA
+    schedule, bit-equal to the exact product; twice on fresh data (a staging race would show as a wrong tile)."""
+    from quantization_amd import build as miq_build
+    monkeypatch.setattr(N, "_lib", N.load(miq_build.DEV_LIB))
+    monkeypatch.setenv("MIQ_GEMM_WIDE_SCHED", sched)
+    for rep, (M, Nn, K, cols) in enumerate([(512, 1152, 384, 3), (256, 1000, 128, 2), (768, 2000, 1024, 4)]):
+        monkeypatch.setenv("MIQ_GEMM_WIDE", str(cols))
+        a, w = rand_i8((M, K), 11 * rep + M).cuda(), rand_i8((Nn, K), 13 * rep + K).cuda()
+        exact = (a.double() @ w.double().T).to(torch.int32)
+        assert torch.equal(N.gemm_i8(a, w, out_dtype=torch.int32), exact)
+        alpha = torch.rand(Nn, device="cuda") * 1e-3 + 1e-5
+        bias = torch.randn(Nn, device="cuda")
+        ref = OC.epilogue_f32(exact.cpu().numpy(), bias.cpu().numpy(), alpha.cpu().numpy(), 0.5)
+        np.testing.assert_array_equal(N.gemm_i8(a, w, bias=bias, alpha=alpha, beta=0.5).cpu().numpy(), ref)
+        yb = N.gemm_i8(a, w, bias=bias, alpha=alpha, beta=0.5, out_dtype=torch.bfloat16)
+        np.testing.assert_array_equal(yb.float().cpu().numpy(), O.round_f32_to_bf16(ref))

@@ -180,7 +180,10 @@ def test_w8f_large_m_tiles(N, xdt):
 def test_w8f_pipelined_256_tile(N, M, Nn, K, xdt, monkeypatch):
     """The software-pipelined 256 x 256 kernel (one or two activation planes), forced through the developer switches so that
     ragged edges in all three dimensions and one-tile problems reach it; each case runs three times on fresh
-    data (a staging race would show as a wrong tile in some run)."""
+    data (a staging race would show as a wrong tile in some run).  The switches exist only in the developer
+    build of the library (same sources, same kernels), which this test loads in place of the product."""
+    from quantization_amd import build as miq_build
+    monkeypatch.setattr(N, "_lib", N.load(miq_build.DEV_LIB))
     monkeypatch.setenv("MIQ_W8F_BM", "256")
     monkeypatch.setenv("MIQ_W8F_BN", "256")
     for rep in range(3):
