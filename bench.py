@@ -7,17 +7,25 @@ epilogue) at M = N = K = 8192 per GPU, the shape BASELINE.json quotes its target
 
 One step = one forward of the layer on int8 activations already resident in HBM, with weights
 produced by the per-channel quantizer from seeded fp32 data.  With N > 1 each rank owns 8192
-output channels of a [8192*N, 8192] layer (weak scaling) and a step also all-gathers the
-[8192, 8192] fp32 output blocks over RCCL, so every rank ends with the full [8192, 8192*N] output;
-the gather of one step overlaps the GEMM of the next (independent layers of a stack).
+output channels of a [8192*N, 8192] layer (weak scaling); a step computes the rank's [8192, 8192]
+block straight into its slot of the gather buffer and all-gathers the blocks in place over RCCL, so
+every rank ends with all N blocks; the gather of one step overlaps the GEMM of the next (independent
+layers of a stack).  What travels is chosen by MIQ_BENCH_GATHER = bf16 (default: the epilogue rounds
+once to bf16, half the bytes), f32 (bit-identical to one GPU) or i8 (requantised with a static
+activation scale, a quarter); `extra.gather_variants` times all three.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job int8 TOPS (2*M*N*K integer operations per
 layer).  `roofline` prices the GEMM kernel against the dense int8 MFMA peak with the kernel's own
-duration measured by HIP events on the launch stream; `extra.quantizer` does the same for the
-quantizer kernel against HBM bandwidth.  `cpu_baseline` is the reference's CPU path (restated in
-oracle/oracle_torch.py, pinned to the reference by fixtures) on a bounded sample of the workload.
+duration measured by HIP events on the launch stream.  `extra` holds the other configurations of
+BASELINE.json, each with its own roofline: the quantizer against HBM bandwidth, the Llama-3-8B MLP at
+one token (config 4), ResNet-18's convolutions at batch 256 (config 3), and `config5`: the
+Llama-3-70B shapes [28672,8192], [8192,28672], [8192,8192] split over the N ranks by output channel
+(strong scaling) at M = 256 / 2048 / 8192 with the GEMM / all-gather breakdown.  `cpu_baseline` is the
+reference's CPU path (restated in oracle/oracle_torch.py, pinned to the reference by fixtures) on a
+bounded sample of the workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,8 +39,10 @@ sys.path.insert(0, ROOT)
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 dense peak of MI355X
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
 
+PREWARM_S = 0.3   # seconds of untimed load before the warm-up steps (clock ramp), reported as prewarm_s
 
-PREWARM_S = 0.3   # seconds of untimed load before the warm-up steps (clock ramp)
+GATHER_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "i8": torch.int8}
+ACT_SCALE = 16.0   # static activation scale of the int8 gather (any positive value costs the same)
 
 
 def event_times(fn, iters):
@@ -45,13 +55,45 @@ def event_times(fn, iters):
     return [s.elapsed_time(e) for s, e in evs]
 
 
+def median_ms(fn, iters=30, warm=20):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = sorted(event_times(fn, iters))
+    return ts[len(ts) // 2]
+
+
+def kernel_source_sha():
+    """Digest of the GEMM kernel's sources: counter results under profiles/ are stamped with it."""
+    h = hashlib.sha256()
+    for f in ("miq_gemm_i8.hip", "miq_gemm_core.h"):
+        with open(os.path.join(ROOT, "quantization_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json), or None."""
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_traffic.json,
+    written by tools/pmc_traffic.sh), or None when that file was measured on other kernel sources than these."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("source_sha") != kernel_source_sha() and kernel.startswith("gemm"):
+            return None
+        return d[kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def hbm_roofline(nbytes, ms):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(nbytes)}
+
+
+def mfma_roofline(ops, ms, peak=PEAK_INT8_TOPS):
+    t = ops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(t, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(t / peak, 4)}
 
 
 def weight_only_float(N_, dev):
@@ -66,58 +108,133 @@ def weight_only_float(N_, dev):
     for M, dt in ((16, torch.bfloat16), (16, torch.float32), (256, torch.bfloat16), (256, torch.float32)):
         x = torch.randn(M, K, device=dev).to(dt)
         out = torch.empty(M, Nn, device=dev)
-
-        def step():
-            N_.gemm_w8(x, w, alpha=alpha, out=out)
-        for _ in range(50):
-            step()
-        torch.cuda.synchronize()
-        ts = sorted(event_times(step, 50))
-        ms = ts[len(ts) // 2]
+        ms = median_ms(lambda: N_.gemm_w8(x, w, alpha=alpha, out=out), 50, 50)
         nbytes = Nn * K + M * K * x.element_size() + M * Nn * 4
         entry = {"call_ms": round(ms, 4), "weight_GBps": round(Nn * K / (ms * 1e-3) / 1e9, 1),
                  "TFLOPs": round(2.0 * M * Nn * K / (ms * 1e-3) / 1e12, 1)}
         if M <= 16:
-            entry["roofline"] = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                 "algorithmic_bytes": nbytes}
+            entry["roofline"] = hbm_roofline(nbytes, ms)
         res[f"M{M}_{str(dt).split('.')[-1]}"] = entry
     return res
 
 
+def llama8b_mlp_decode(N_, dev):
+    """BASELINE config 4 at one token: the three int8 matmuls of a Llama-3-8B MLP (gate, up [14336,4096]; down
+    [4096,14336]) with the fused dequant epilogue, M = 1 and M = 16, fp32 out.  A step is bound by reading the
+    three int8 weights once: algorithmic bytes = 3 * 14336 * 4096 + activations + outputs."""
+    shapes = (("gate", 14336, 4096), ("up", 14336, 4096), ("down", 4096, 14336))
+    ws = {n: (torch.randint(-128, 128, (r, c), dtype=torch.int32, device=dev).to(torch.int8),
+              torch.rand(r, device=dev) * 0.01) for n, r, c in shapes}
+    res = {"weights": "int8 gate/up [14336,4096], down [4096,14336]", "out_dtype": "float32"}
+    for M in (1, 16):
+        xa = torch.randint(-128, 128, (M, 4096), dtype=torch.int32, device=dev).to(torch.int8)
+        xd = torch.randint(-128, 128, (M, 14336), dtype=torch.int32, device=dev).to(torch.int8)
+        outs = {n: torch.empty(M, r, device=dev) for n, r, c in shapes}
+
+        def step():
+            for n, r, c in shapes:
+                N_.gemm_i8(xd if n == "down" else xa, ws[n][0], alpha=ws[n][1], out=outs[n])
+        ms = median_ms(step, 50, 50)
+        nbytes = sum(r * c + M * c + 4 * M * r for _, r, c in shapes)
+        res[f"M{M}"] = {"step_ms": round(ms, 4), "weight_GBps": round(3 * 14336 * 4096 / (ms * 1e-3) / 1e9, 1),
+                        "roofline": hbm_roofline(nbytes, ms)}
+    return res
+
+
+RESNET18_CONVS = [  # (Cin, H, Cout, k, stride, pad, occurrences in ResNet-18)
+    (3, 224, 64, 7, 2, 3, 1), (64, 56, 64, 3, 1, 1, 4), (64, 56, 128, 3, 2, 1, 1), (128, 28, 128, 3, 1, 1, 3),
+    (64, 56, 128, 1, 2, 0, 1), (128, 28, 256, 3, 2, 1, 1), (256, 14, 256, 3, 1, 1, 3), (128, 28, 256, 1, 2, 0, 1),
+    (256, 14, 512, 3, 2, 1, 1), (512, 7, 512, 3, 1, 1, 3), (256, 14, 512, 1, 2, 0, 1)]
+
+
 def conv_int8(N_, dev):
-    """The int8 Conv2d (miq_conv2d_i8) on two ResNet-18 layers at batch 256, int32 out: whole call (re-layout
-    launch + implicit-GEMM kernel), HIP events per call, outputs rotating over three buffers.  The large-image
-    layer is priced against HBM bandwidth on its algorithmic bytes (int8 input and weight once + the int32
-    output), the 14 x 14 layer against the dense int8 MFMA peak on 2*B*Cout*Ho*Wo*Cin*9."""
-    res = {"batch": 256, "out_dtype": "int32"}
-    for C, H, Co, bound in ((64, 56, 64, "hbm"), (256, 14, 256, "mfma")):
-        x = torch.randint(-128, 128, (256, C, H, H), dtype=torch.int32, device=dev).to(torch.int8)
-        w = torch.randint(-128, 128, (Co, C, 3, 3), dtype=torch.int32, device=dev).to(torch.int8)
-        outs = [torch.empty(256, Co, H, H, dtype=torch.int32, device=dev) for _ in range(3)]
+    """BASELINE config 3: ResNet-18's twenty convolutions at batch 256 (miq_conv2d_i8, int8 NCHW in, int32 NCHW out):
+    whole call (re-layout launch + implicit-GEMM kernel), HIP events per call, outputs rotating over three buffers.
+    Two layers are itemised (the large-image one against HBM bandwidth on int8 input + weight once + int32 output,
+    the 14 x 14 one against the int8 MFMA peak); `stack` is the sum over all twenty, against the MFMA peak."""
+    B = 256
+    res = {"batch": B, "out_dtype": "int32"}
+    total_ms, total_ops = 0.0, 0.0
+    for C, H, Co, k, s, p, times in RESNET18_CONVS:
+        x = torch.randint(-128, 128, (B, C, H, H), dtype=torch.int32, device=dev).to(torch.int8)
+        w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device=dev).to(torch.int8)
+        Ho = (H + 2 * p - k) // s + 1
+        outs = [torch.empty(B, Co, Ho, Ho, dtype=torch.int32, device=dev) for _ in range(3)]
         it = [0]
 
         def step():
-            N_.conv2d_i8(x, w, 1, 1, out_dtype=torch.int32, out=outs[it[0] % 3])
+            N_.conv2d_i8(x, w, s, p, out_dtype=torch.int32, out=outs[it[0] % 3])
             it[0] += 1
-        for _ in range(50):
-            step()
-        torch.cuda.synchronize()
-        ts = sorted(event_times(step, 50))
-        ms = ts[len(ts) // 2]
-        ops = 2.0 * 256 * Co * H * H * C * 9
-        nbytes = x.numel() + w.numel() + 4 * outs[0].numel()
-        entry = {"call_ms": round(ms, 4), "TOPS": round(ops / (ms * 1e-3) / 1e12, 1)}
-        if bound == "hbm":
-            entry["roofline"] = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                 "algorithmic_bytes": nbytes}
-        else:
-            entry["roofline"] = {"bound": "mfma", "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": PEAK_INT8_TOPS,
-                                 "unit": "TFLOP/s", "frac": round(ops / (ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4)}
-        res[f"{C}to{Co}_{H}x{H}_k3s1"] = entry
+        ms = median_ms(step, 30, 30)
+        ops = 2.0 * B * Co * Ho * Ho * C * k * k
+        total_ms += ms * times
+        total_ops += ops * times
+        if (C, H, Co, k) in ((64, 56, 64, 3), (256, 14, 256, 3)):
+            entry = {"call_ms": round(ms, 4), "TOPS": round(ops / (ms * 1e-3) / 1e12, 1)}
+            if H == 56:
+                entry["roofline"] = hbm_roofline(x.numel() + w.numel() + 4 * outs[0].numel(), ms)
+            else:
+                entry["roofline"] = mfma_roofline(ops, ms)
+            res[f"{C}to{Co}_{H}x{H}_k{k}s{s}"] = entry
         del x, w, outs
+    res["stack"] = {"layers": 20, "total_ms": round(total_ms, 4), "TOPS": round(total_ops / (total_ms * 1e-3) / 1e12, 1),
+                    "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms)}
     return res
+
+
+def config5(N_, dev, world, rank, dist, m_list=(256, 2048, 8192)):
+    """BASELINE config 5: Llama-3-70B linear shapes split by output channel over the `world` ranks (strong scaling:
+    the layer is fixed, each rank owns N / world channels), int8 activations, bf16 epilogue output written straight
+    into the gather buffer, in-place all-gather.  Per shape and M: the local GEMM (HIP events, median), the
+    all-gather alone (host clock around issue + wait, median) and both in sequence; bytes received per GPU =
+    (g-1)/g * M * N * sizeof(out).  Times are the maximum over ranks."""
+    from quantization_amd.sharded import ColumnShardedLinear
+    rows = []
+    for n, k in ((28672, 8192), (8192, 28672), (8192, 8192)):
+        n_local = n // world   # every shape divides by 1, 2, 4, 8
+        wq = torch.randint(-128, 128, (n_local, k), dtype=torch.int32, device=dev).to(torch.int8)
+        scale = torch.rand(n_local, device=dev) * 0.01 + 1e-4
+        layer = ColumnShardedLinear(wq, scale, None, n, out_dtype=torch.bfloat16)
+        for M in m_list:
+            if rank == 0:
+                print(f"[bench] config 5: [{n},{k}] over {world} rank(s), M={M}", file=sys.stderr, flush=True)
+            x = torch.randint(-128, 128, (M, k), dtype=torch.int32, device=dev).to(torch.int8)
+            gemm_ms = median_ms(lambda: layer.compute_block(x), 9, 5)
+            got = layer.compute_block(x)
+            gather, both = [], []
+            for _ in range(7 if world > 1 else 1):
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                layer.start_gather(got).wait()
+                torch.cuda.synchronize()
+                gather.append((time.perf_counter() - t0) * 1e3)
+            for _ in range(7):
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                layer.gather_async(x).wait()
+                torch.cuda.synchronize()
+                both.append((time.perf_counter() - t0) * 1e3)
+            t = torch.tensor([gemm_ms, sorted(gather)[len(gather) // 2], sorted(both)[len(both) // 2]], device=dev,
+                             dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gemm_ms, gather_ms, layer_ms = (float(v) for v in t.tolist())
+            recv = (world - 1) * M * n_local * 2
+            rows.append({"shape": f"[{n},{k}]", "M": M, "n_local": n_local, "gemm_ms": round(gemm_ms, 4),
+                         "gather_ms": round(gather_ms, 4) if world > 1 else 0.0, "layer_ms": round(layer_ms, 4),
+                         "gemm_TOPS_per_gpu": round(2.0 * M * n_local * k / (gemm_ms * 1e-3) / 1e12, 1),
+                         "layer_TOPS_all_gpus": round(2.0 * M * n * k / (layer_ms * 1e-3) / 1e12, 1),
+                         "bytes_received_per_gpu": recv,
+                         "gather_GBps_per_gpu": round(recv / (gather_ms * 1e-3) / 1e9, 1) if world > 1 else None})
+            del x, got
+        del layer, wq
+        torch.cuda.empty_cache()
+    return {"workload": "Llama-3-70B linear shapes, output channels split over the ranks, int8 activations, "
+                        "bf16 output gathered in place", "gather_dtype": "bfloat16", "ranks": world, "cases": rows}
 
 
 def cpu_baseline(K, N, sample_rows, seed):
@@ -161,6 +278,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=8192, help="M = N(per GPU) = K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline step (no config 3/4/5 extras)")
+    ap.add_argument("--config5-m", default="256,2048,8192", help="token counts of the config-5 breakdown (a rehearsal over "
+                    "gloo on one GPU moves every gathered byte through the host: give it 256)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,29 +337,56 @@ def main():
     del ws
     wq, scale, _ = N_.quantize_rows_sym_i8(w_local)
 
-    layer = ColumnShardedLinear(wq, scale, bias_local, n_total, out_dtype=torch.float32)
+    gather_name = os.environ.get("MIQ_BENCH_GATHER", "bf16" if world > 1 else "f32")
+    if gather_name not in GATHER_DTYPES:
+        sys.exit(f"MIQ_BENCH_GATHER must be one of {sorted(GATHER_DTYPES)}")
 
-    def run_steps(n, events=None):
+    def make_layer(name):
+        dt = GATHER_DTYPES[name]
+        return ColumnShardedLinear(wq, scale, bias_local, n_total, out_dtype=torch.float32 if dt == torch.int8 else dt,
+                                   gather_dtype=dt, act_scale=ACT_SCALE if dt == torch.int8 else None)
+
+    def run_steps(layer, n, events=None):
         """n forwards of the layer.  The all-gather of step i runs on RCCL's stream while the GEMM of
-        step i+1 runs on the compute stream (the steps are independent layers of a stack); at most two
-        gathers are in flight, and every one has completed when this returns.  `events` collects a HIP
-        event pair around every GEMM launch, on the stream it is launched on."""
-        pending = None
-        for _ in range(n):
+        step i+1 runs on the compute stream (the steps are independent layers of a stack); two gather
+        buffers alternate, and a buffer is written again only after its previous gather has completed.
+        Every gather has completed when this returns.  `events` collects a HIP event pair around every
+        GEMM launch, on the stream it is launched on."""
+        pending = [None, None]
+        for i in range(n):
+            slot = i & 1
+            if pending[slot] is not None:
+                pending[slot].wait()
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            y = layer.local_forward(x)
+            got = layer.compute_block(x, slot)
             if events is not None:
                 e1.record()
                 events.append((e0, e1))
-            _, work = layer.gather_async(y)
-            if pending is not None:
-                pending.wait()
-            pending = work
-        if pending is not None:
-            pending.wait()
+            pending[slot] = layer.start_gather(got)
+        for p in pending:
+            if p is not None:
+                p.wait()
 
+    def timed(layer, steps, warmup, events=None):
+        run_steps(layer, warmup)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(layer, steps, events)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    layer = make_layer(gather_name)
     # The chip takes tens of milliseconds of load to leave its idle clocks (the same 30 steps measured
     # 0.456 ms each after 5 warm-up steps and 0.408 ms after 100): bring it to its loaded state with the
     # same step before the W warm-up steps, whatever W the caller asks for.
@@ -247,33 +394,41 @@ def main():
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < PREWARM_S:
         for _ in range(10):
-            layer.local_forward(x)
+            layer.compute_block(x)
         torch.cuda.synchronize()
-    run_steps(args.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     gemm_events = []
-    run_steps(args.steps, gemm_events)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(layer, args.steps, args.warmup, gemm_events)
 
     # --- GEMM kernel duration: the event pairs recorded around every launch of the timed region ----
     kt = [a.elapsed_time(b) for a, b in gemm_events]
     k_ms = sum(kt) / len(kt)
     ops_layer = 2.0 * M * S * K
 
+    extras = {}
+    if not args.no_extras:
+        if world > 1:
+            variants = {}
+            for name in ("f32", "bf16", "i8"):
+                if rank == 0:
+                    print(f"[bench] headline step with the {name} gather", file=sys.stderr, flush=True)
+                lay = layer if name == gather_name else make_layer(name)
+                el = elapsed if name == gather_name else timed(lay, max(args.steps // 4, 5), 3)
+                st = args.steps if name == gather_name else max(args.steps // 4, 5)
+                recv = (world - 1) * M * S * torch.empty(0, dtype=GATHER_DTYPES[name]).element_size()
+                variants[name] = {"ms_per_step": round(el / st * 1e3, 4), "TOPS": round(ops_layer * world / (el / st) / 1e12, 1),
+                                  "bytes_received_per_gpu_per_step": recv,
+                                  "GBps_per_gpu_if_step_were_only_the_gather": round(recv / (el / st) / 1e9, 1)}
+                if lay is not layer:
+                    del lay
+                    torch.cuda.empty_cache()
+            extras["gather_variants"] = variants
+        extras["config5"] = config5(N_, dev, world, rank, dist, tuple(int(v) for v in args.config5_m.split(",")))
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = ops_layer * world / (ms_per_step * 1e-3) / 1e12
         achieved = ops_layer / (k_ms * 1e-3) / 1e12
+        out_name = {"f32": "float32", "bf16": "bfloat16", "i8": "float32 -> int8 (static activation scale)"}[gather_name]
         line = {
             "metric": "int8 linear TOPS (M=N=K=8192, fused per-channel dequant epilogue)",
             "value": round(value, 1),
@@ -281,6 +436,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_s": PREWARM_S,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -290,11 +446,13 @@ def main():
             "config": {
                 "workload": f"int8 linear M={M} N={S} per GPU ({n_total} total) K={K}, int8 activations x "
                             "per-channel-quantized int8 weights -> int32 MFMA accumulate -> fused "
-                            "(acc+bias)*scale fp32 epilogue"
-                            + ("" if world == 1 else f"; column-sharded over {world} GPUs + RCCL all-gather of the fp32 output"),
-                "M": M, "N_per_gpu": S, "K": K, "out_dtype": "float32",
-                "parallelism": "single GPU" if world == 1 else f"column-sharded x{world} + all-gather",
+                            f"(acc+bias)*scale epilogue, {out_name} out"
+                            + ("" if world == 1 else f"; column-sharded over {world} GPUs + in-place RCCL all-gather of the "
+                                                     f"{gather_name} blocks, overlapped with the next step's GEMM"),
+                "M": M, "N_per_gpu": S, "K": K, "out_dtype": out_name,
+                "parallelism": "single GPU" if world == 1 else f"column-sharded x{world} + all-gather ({gather_name})",
                 "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
+                "untimed_before_warmup": f"{PREWARM_S} s of the same GEMM (clock ramp) on top of --warmup",
             },
             "roofline": {
                 "bound": "mfma",
@@ -306,40 +464,32 @@ def main():
                 "kernel": "gemm_i8_256_kernel",
                 "kernel_ms": round(k_ms, 4),
                 "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch; "
-                        "traffic = bytes per launch through the L2 <-> fabric ports from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in "
-                        "profiles/ (an upper bound of HBM bytes: it counts the fills of the eight per-XCD L2s, 8 XCDs x 4 rounds "
-                        "x 12 operand panels x 2 MiB = 768 MiB of first touches per launch, most of which the 256 MiB Infinity "
-                        "Cache serves; the operands themselves are 128 MiB, the output 256 MiB)",
+                        "traffic = bytes per launch through the L2 <-> fabric ports from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
+                        "passes recorded in profiles/r2_traffic.json for exactly these kernel sources (null otherwise); an upper "
+                        "bound of HBM bytes: it counts the fills of the eight per-XCD L2s, most of which the 256 MiB Infinity "
+                        "Cache serves (the operands themselves are 128 MiB, the output 256 MiB).  The kernel is power-limited on "
+                        "random int8 operands: the chip holds ~1.9 GHz under it against 2.4 GHz on zeros (profiles/r2_gemm_wide.txt)",
             },
             "extra": {
                 "quantizer": {
                     "workload": f"per-channel symmetric int8 quantize of fp32 [{QR},{QC}] (5 B/element + 12 B/row)",
                     "GBps": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
                     "kernel_ms": round(q_ms, 4),
-                    "roofline": {"bound": "hbm", "achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
-                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(q_bytes / (q_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                 "traffic": profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None,
-                                 "algorithmic_bytes": q_bytes},
+                    "roofline": dict(hbm_roofline(q_bytes, q_ms),
+                                     traffic=profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None),
                 },
             },
         }
-        if world > 1:
-            # what the step is bound by at N > 1: every rank receives the other ranks' fp32 blocks over xGMI
-            recv = (world - 1) * M * S * 4
-            line["extra"]["allgather"] = {
-                "bytes_received_per_gpu_per_step": recv,
-                "GBps_per_gpu_if_step_were_only_the_gather": round(recv / (ms_per_step * 1e-3) / 1e9, 1),
-                "gemm_kernel_ms": round(k_ms, 4),
-                "note": "the all-gather of step i overlaps the GEMM of step i+1; a step costs max(gather, GEMM)",
-            }
-        if world == 1:
+        line["extra"].update(extras)
+        if world == 1 and not args.no_extras:
+            line["extra"]["llama3_8b_mlp_decode"] = llama8b_mlp_decode(N_, dev)
             line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
             line["extra"]["conv_int8"] = conv_int8(N_, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -188,7 +188,12 @@ def config1_models(mods):
         model = ctor().eval()
         fp = {n: mod.weight.detach().clone() for n, mod in model.named_modules()
               if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear))}
+        x = loader(1, 2, 11)[0][0]
+        with torch.no_grad():
+            out[mname + "/y_fp"] = as_f32(model(x))            # the float model, before the rewrite
         qmodel = mods["Chunker"].Chunker(model, loader(1, 2, 11)).model
+        with torch.no_grad():
+            out[mname + "/y_quant"] = as_f32(qmodel(x))        # the reference flow: Chunker(model).model, then a forward
         names = []
         for n, mod in qmodel.named_modules():
             if type(mod).__name__ != "Quantizer":
@@ -297,6 +302,11 @@ def main():
         wo = load_ref("Weight_Only")
         np.savez_compressed(os.path.join(OUT, "wo_forward.npz"), **wo_forward_cases(wo))
         print("wo_forward.npz", os.path.getsize(os.path.join(OUT, "wo_forward.npz")))
+        return
+    if sys.argv[1:] == ["config1"]:
+        wo = load_ref("Weight_Only")
+        np.savez_compressed(os.path.join(OUT, "config1_models.npz"), **config1_models(wo))
+        print("wrote config1_models.npz")
         return
     if sys.argv[1:] == ["pools"]:
         wa = load_ref("Weight_Activation")

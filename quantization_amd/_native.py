@@ -151,6 +151,8 @@ def quantize_rows_sym_i8(w, want_row_max=False):
 def row_max(w):
     """Signed maximum of every w[n, ...] as fp32 [N]."""
     require_device(w, "tensor")
+    if w.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"unsupported weight dtype {w.dtype}")
     rows = w.shape[0]
     cols = w.numel() // rows if rows else 0
     out = torch.empty(rows, dtype=torch.float32, device=w.device)
@@ -159,9 +161,11 @@ def row_max(w):
     return out
 
 
-def quantize_rows_given_i8(w, scale, zp=None):
+def quantize_rows_given_i8(w, scale, zp=None, out=None):
     """q = int8(clamp(rint(w / scale + zp))) with scale/zp of `rows` entries or one."""
     require_device(w, "tensor")
+    if w.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"unsupported weight dtype {w.dtype}")
     rows = w.shape[0]
     cols = w.numel() // rows if rows else 0
     scale = scale.detach().reshape(-1).to(device=w.device, dtype=torch.float32).contiguous()
@@ -172,7 +176,13 @@ def quantize_rows_given_i8(w, scale, zp=None):
         zp = zp.detach().reshape(-1).to(device=w.device, dtype=torch.float32).contiguous()
         if zp.numel() != scale.numel():
             raise RuntimeError("zero_point and scales must have the same number of entries")
-    q = torch.empty(w.shape, dtype=torch.int8, device=w.device)
+    if out is None:
+        q = torch.empty(w.shape, dtype=torch.int8, device=w.device)
+    else:
+        require_device(out, "out")
+        if out.numel() != w.numel() or out.dtype != torch.int8 or out.device != w.device:
+            raise RuntimeError("out has the wrong size, dtype or device")
+        q = out
     with _on(w.device):
         _check(lib().miq_quantize_rows_given_i8(_ptr(w), _FLOAT_CODES[w.dtype], rows, cols, _ptr(scale), _ptr(zp),
                                                 per_row, _ptr(q), _stream()))
@@ -391,14 +401,21 @@ def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
         raise RuntimeError(f"shape mismatch: input has {C} channels, kernel expects {Ci}")
     if out_dtype not in _OUT_CODES:
         raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    stride, padding = int(stride), int(padding)
+    if stride < 1 or padding < 0:
+        raise RuntimeError(f"bad stride / padding ({stride}, {padding})")
     Ho = (H + 2 * padding - KH) // stride + 1
     Wo = (W + 2 * padding - KW) // stride + 1
-    if Ho <= 0 or Wo <= 0:
+    if H + 2 * padding < KH or W + 2 * padding < KW or Ho <= 0 or Wo <= 0:
         raise RuntimeError("kernel larger than the padded input")
     bias = _f32_vec(bias, Co, "bias", x.device)
     alpha = _f32_vec(alpha, Co, "alpha", x.device)
     if out is None:
         out = torch.empty((B, Co, Ho, Wo), dtype=out_dtype, device=x.device)
+    else:
+        require_device(out, "out")
+        if tuple(out.shape) != (B, Co, Ho, Wo) or out.dtype != out_dtype or out.device != x.device:
+            raise RuntimeError("out has the wrong shape, dtype or device")
     L = lib()
     need = L.miq_conv2d_i8_workspace(B, C, H, W, Co, KH, KW, stride, padding)
     ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)

@@ -11,6 +11,7 @@ forward():
 Host tensors are staged to the GPU and results returned to the caller's device.
 """
 import functools
+import warnings
 
 import torch
 import torch.nn as nn
@@ -53,14 +54,33 @@ class _QuantizerBase(nn.Module):
         self.register_buffer("weight", torch.zeros(self.weight_shape, dtype=torch.int8))
         self._wfloat = None
         self._wfloat_src = None
+        self._gpu_cache = {}      # device copies of host-resident weight / bias / scales, keyed by role
+        self._beta_cache = None   # (output_zero_point tensor, its version, the value as a Python float)
+        self._params_stale = None # set to a message when a checkpoint without quantization parameters was loaded
 
     def to(self, *args, **kwargs):
         super().to(*args, **kwargs)
         self.weight = self.weight.to(*args, **kwargs)
         if self.bias is not None:
             self.bias = self.bias.to(*args, **kwargs)
-        self._wfloat = None
+        self._invalidate()
         return self
+
+    def _invalidate(self):
+        self._wfloat = None
+        self._gpu_cache = {}
+        self._beta_cache = None
+
+    def _on_gpu(self, role, t):
+        """`t` on the GPU.  A module kept on the host would otherwise upload its whole int8 weight (and bias,
+        scales) on every forward: the device copy is kept until the tensor is replaced or written in place."""
+        if t is None or t.is_cuda:
+            return t
+        ent = self._gpu_cache.get(role)
+        if ent is None or ent[0] is not t or ent[1] != t._version:
+            ent = (t, t._version, _to_gpu(t.detach()))
+            self._gpu_cache[role] = ent
+        return ent[2]
 
     # ---- persisted quantization parameters ------------------------------------------------
     # The reference's state_dict carries the int8 `weight` buffer only: its scales live on a plain
@@ -82,19 +102,29 @@ class _QuantizerBase(nn.Module):
     def set_extra_state(self, state):
         dev = self.weight.device
         self._set_quant_state({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in state.items()})
-        self._wfloat = None
+        self._params_stale = None
+        self._invalidate()
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
+        self._invalidate()
         key = prefix + "_extra_state"
         if key in missing_keys:
+            # A checkpoint the reference wrote: the int8 weight without its scales.  It loads (the keys it has are
+            # the reference's), but the scales this module holds belong to OTHER weights: refuse to run with
+            # them until the caller supplies the parameters (set_extra_state / re-quantize / re-calibrate).
             missing_keys.remove(key)
+            if prefix + "weight" in state_dict:
+                self._params_stale = (f"{prefix or 'layer'}: the loaded state_dict carries an int8 weight but no "
+                                      "quantization parameters (no '_extra_state' entry); the scales held by this "
+                                      "module were computed from different weights")
+                warnings.warn(self._params_stale + " -- forward() will raise until they are set", stacklevel=2)
 
     # ---- the two products -------------------------------------------------------------
     def _int8_product(self, x, bias, alpha, beta):
-        w = _to_gpu(self.weight)
+        w = self._on_gpu("weight", self.weight)
         if self.cnn:
             if _single(self.dilation) != 1 or self.groups != 1:
                 raise NotImplementedError("the int8 convolution implements dilation 1, groups 1")
@@ -107,7 +137,7 @@ class _QuantizerBase(nn.Module):
         return y.view(*lead, y.shape[-1])
 
     def _float_product(self, x, bias, alpha, beta):
-        w = _to_gpu(self.weight)
+        w = self._on_gpu("weight", self.weight)
         if not self.cnn:
             # Linear: the int8 weight goes to the matrix cores as it is stored (no float copy of it), with the
             # bias / scale epilogue fused (miq_gemm_w8).
@@ -132,8 +162,11 @@ class _QuantizerBase(nn.Module):
         return _native.epilogue_channels_f32(y.contiguous(), bias, alpha, beta)
 
     def _run(self, x, bias, alpha, beta):
+        if self._params_stale:
+            raise RuntimeError(self._params_stale)
         home = x.device
         xd = _to_gpu(x).contiguous()
+        bias, alpha = self._on_gpu("bias", bias), self._on_gpu("alpha", alpha)
         if xd.dtype == torch.int8:
             y = self._int8_product(xd, bias, alpha, beta)
         elif xd.dtype.is_floating_point:
@@ -186,6 +219,9 @@ class WeightOnlyQuantizer(_QuantizerBase):
         self.input_quant = False
         self.input_quantizer = QopWeightOnly(dtype=torch.uint8, symmetric=False, affine='tensor', affine_dim=None)
         self.input_quantizer.max_val = 127
+        # Part of the reference's attribute surface (Quantizer.py:45-47); its forward never calls it.
+        self.input_observer = torch.ao.quantization.observer.MinMaxObserver(dtype=torch.quint8,
+                                                                            qscheme=torch.per_tensor_affine)
         self.weight_quant = QopWeightOnly(
             dtype=data_metrics['weights']['dtype'],
             symmetric=data_metrics['weights']['symmetric'],
@@ -205,8 +241,10 @@ class WeightOnlyQuantizer(_QuantizerBase):
             # tensor and take the int8 product (see quantization_amd/activation.py).  Linear only: an
             # asymmetric activation needs its zero point, not 0, as the convolution's padding value.
             from .activation import linear_dynamic_w8a8, weight_rowsum
+            if self._params_stale:
+                raise RuntimeError(self._params_stale)
             home = x.device
-            w = _to_gpu(self.weight)
+            w = self._on_gpu("weight", self.weight)
             if getattr(self, "_rowsum_src", None) is not self.weight:
                 self._rowsum, self._rowsum_src = weight_rowsum(w), self.weight
             bias = None if self.bias is None else _to_gpu(self.bias.detach())
@@ -303,9 +341,19 @@ class WeightActivationQuantizer(_QuantizerBase):
         bias = self.bias
         if bias is not None and bias.numel() == 1 and n != 1:
             bias = bias.reshape(1).expand(n)  # `torch.tensor(0)` stands for "no bias" (Quantizer.py:81)
+        return self._run(x, bias, self.scalers, self._beta())
+
+    def _beta(self):
+        """output_zero_point as a Python float.  Reading it from a GPU tensor blocks the host, so it is read once
+        per value (when the tensor is replaced or written) and not on every forward: a layer's forward then
+        only enqueues work, and captures into a HIP graph."""
         ozp = self.output_zero_point
-        beta = float(ozp.reshape(-1)[0]) if isinstance(ozp, torch.Tensor) else float(ozp)
-        return self._run(x, bias, self.scalers, beta)
+        if not isinstance(ozp, torch.Tensor):
+            return float(ozp)
+        c = self._beta_cache
+        if c is None or c[0] is not ozp or c[1] != ozp._version:
+            c = self._beta_cache = (ozp, ozp._version, float(ozp.reshape(-1)[0]))
+        return c[2]
 
     _STATE = ("bias", "weight_qscale", "weight_zero_point", "scalers", "output_zero_point")
 

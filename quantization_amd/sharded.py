@@ -5,8 +5,22 @@ column of the output (the reference quantizes row by row: quant/Weight_Only/Qop.
 rank r of g keeps rows [lo_r, hi_r) of W[N,K] and computes out[:, lo_r:hi_r] with no
 communication; the quantizer needs none either.  The single exchange is an all-gather of the
 [M, N/g] output blocks (RCCL over xGMI through torch.distributed's "nccl" backend).  The
-reference has no multi-GPU code; the gathered result is bit-identical to the single-GPU one
+reference has no multi-GPU code; the gathered fp32 result is bit-identical to the single-GPU one
 because no accumulation order changes.
+
+Data movement.  The GEMM writes its block straight into this rank's slot of the gather buffer and
+the all-gather runs in place on that buffer (input = the rank's slot of the output), so a layer
+costs one kernel, one collective, no padding pass and no staging copy.  The buffer is cached per
+(rows, dtype).  The gathered result is the list of the ranks' column blocks, `blocks()`: block r
+is the dense [M, n_r] matrix out[:, lo_r:hi_r].  A single row-major [M, N] matrix needs the blocks
+interleaved row by row, which a collective over contiguous chunks cannot place: `to_dense()` pays
+one pass for callers that want it.
+
+What travels.  `gather_dtype` chooses the bytes on the links: the output dtype itself (fp32:
+bit-identical to one GPU), bfloat16 (half the bytes; the epilogue rounds once), or int8 (a
+quarter): the block is requantised with a static activation scale, x_q = clamp(rint(y / act_scale)),
+the per-tensor form of Qop.quantize (quant/Weight_Only/Qop.py:154-157), which is what a following
+int8 layer consumes.
 
 Layers of a stack that read the same activations are independent, so the all-gather of layer i
 runs on the communication stream while the GEMM of layer i+1 runs on the compute stream.
@@ -29,15 +43,45 @@ def _quantize_hip(w):
     return q, scale
 
 
+class Gathered:
+    """The ranks' column blocks of one layer's output, in the gather buffer [g, M * n_max]."""
+
+    def __init__(self, buf, rows, out_features, work=None):
+        self.buf, self.rows, self.out_features, self.work = buf, rows, out_features, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self
+
+    def blocks(self):
+        """[out[:, lo_r:hi_r] for r in ranks]: dense [M, n_r] views of the buffer, no copy."""
+        self.wait()
+        g, M = self.buf.shape[0], self.rows
+        views = []
+        for r in range(g):
+            lo, hi = shard_rows(self.out_features, g, r)
+            views.append(self.buf[r, :M * (hi - lo)].view(M, hi - lo))
+        return views
+
+    def to_dense(self):
+        """The [M, N] matrix a single GPU would have produced (one pass over the output)."""
+        b = self.blocks()
+        return b[0] if len(b) == 1 else torch.cat(b, dim=1)
+
+
 class ColumnShardedLinear:
-    """This rank's slice of a weight-only int8 Linear, plus the gather that rebuilds [M, N].
+    """This rank's slice of a weight-only int8 Linear, plus the gather that rebuilds the output.
 
     weight_q [n_local, K] int8, scale [n_local] fp32, bias [n_local] fp32 or None are the slices
     for rows shard_rows(out_features, world, rank).  `gemm(x, w, bias=, alpha=, beta=, out_dtype=)`
-    is the product + epilogue; it defaults to the HIP int8 GEMM.
+    is the product + epilogue; it defaults to the HIP kernels (and then writes in place).
+    gather_dtype: None (= out_dtype), torch.bfloat16, or torch.int8 (needs act_scale > 0).
     """
 
-    def __init__(self, weight_q, scale, bias, out_features, group=None, out_dtype=torch.float32, gemm=None):
+    def __init__(self, weight_q, scale, bias, out_features, group=None, out_dtype=torch.float32, gemm=None,
+                 gather_dtype=None, act_scale=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -46,77 +90,110 @@ class ColumnShardedLinear:
         if weight_q.shape[0] != self.hi - self.lo:
             raise RuntimeError(f"rank {self.rank} owns rows [{self.lo},{self.hi}) but was given {weight_q.shape[0]}")
         self.weight, self.scale, self.bias = weight_q, scale, bias
+        self.gather_dtype = gather_dtype or out_dtype
+        if self.gather_dtype == torch.int8:
+            if act_scale is None or not act_scale > 0:
+                raise RuntimeError("an int8 gather needs the activation scale (act_scale > 0)")
+            self.act_scale = torch.tensor([float(act_scale)], dtype=torch.float32)
+            out_dtype = torch.float32          # the epilogue's fp32 result is what gets requantised
+        elif self.gather_dtype == torch.bfloat16:
+            out_dtype = torch.bfloat16         # the epilogue rounds once, straight into the slot
+        elif self.gather_dtype != out_dtype:
+            raise RuntimeError(f"gather_dtype must be None, bfloat16 or int8 (got {gather_dtype})")
         self.out_dtype = out_dtype
         self.n_max = -(-out_features // self.world)
-        self._gemm = gemm or _native.gemm_i8
-        self._custom_gemm = gemm is not None
+        self._gemm = gemm
+        self._bufs = {}
 
     @classmethod
-    def from_float(cls, weight, bias=None, group=None, out_dtype=torch.float32, gemm=None, quantize=None):
-        """Quantize this rank's rows of a full fp weight [N, K] (each rank may also pass only
-        its own rows with `weight.shape[0] == hi - lo`, which is how large models are loaded)."""
+    def from_float(cls, weight, bias=None, group=None, out_dtype=torch.float32, gemm=None, quantize=None,
+                   out_features=None, **kw):
+        """Quantize this rank's rows of an fp weight.  `weight` is the full [N, K] matrix (this rank's
+        rows are sliced out of it and of `bias`), or, with `out_features=N` given, only this rank's
+        rows [hi - lo, K] and bias entries: how large models are loaded, no rank ever holding N x K floats."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        n = weight.shape[0]
-        lo, hi = shard_rows(n, world, rank)
-        q, scale = (quantize or _quantize_hip)(weight[lo:hi])
-        b = None if bias is None else bias[lo:hi].to(torch.float32).contiguous()
-        return cls(q, scale, b, n, group=group, out_dtype=out_dtype, gemm=gemm)
+        if out_features is None:
+            n = weight.shape[0]
+            lo, hi = shard_rows(n, world, rank)
+            weight = weight[lo:hi]
+            bias = None if bias is None else bias[lo:hi]
+        else:
+            n = out_features
+            lo, hi = shard_rows(n, world, rank)
+            if weight.shape[0] != hi - lo or (bias is not None and bias.shape[0] != hi - lo):
+                raise RuntimeError(f"rank {rank} owns rows [{lo},{hi}) of {n}: expected {hi - lo} rows, got {weight.shape[0]}")
+        q, scale = (quantize or _quantize_hip)(weight)
+        b = None if bias is None else bias.to(torch.float32).contiguous()
+        return cls(q, scale, b, n, group=group, out_dtype=out_dtype, gemm=gemm, **kw)
 
-    def local_forward(self, x):
-        """out[:, lo:hi] for activations x [M, K] replicated on every rank: int8 (int8 product) or floating point
-        (the weight-only product on the int8 weight as stored)."""
-        if self._custom_gemm or x.dtype == torch.int8:
-            return self._gemm(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype)
-        return _native.gemm_w8(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype)
+    # ---- buffers ----------------------------------------------------------------------------
+    def _gather_buffer(self, M, device, slot=0):
+        """[g, M * n_max] of gather_dtype, reused call after call (`slot` tells apart the buffers of layers
+        whose gathers are in flight at the same time)."""
+        key = (M, device, slot)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = self._bufs[key] = torch.empty((self.world, M * self.n_max), dtype=self.gather_dtype, device=device)
+        return buf
 
-    def gather_async(self, y_local):
-        """Start the all-gather of the ranks' column blocks.  Returns (buffer [g, M, n_max], work)."""
-        M = y_local.shape[0]
-        if self.world == 1:
-            return y_local.unsqueeze(0), None
-        if y_local.shape[1] != self.n_max:  # ragged split: pad the narrower blocks
-            padded = y_local.new_zeros((M, self.n_max))
-            padded[:, :y_local.shape[1]] = y_local
-            y_local = padded
-        buf = torch.empty((self.world, M, self.n_max), dtype=y_local.dtype, device=y_local.device)
-        # the output is the ranks' blocks concatenated along dim 0: [g*M, n_max]
-        work = dist.all_gather_into_tensor(buf.view(self.world * M, self.n_max), y_local.contiguous(),
-                                           group=self.group, async_op=True)
-        return buf, work
+    def _product(self, x, out):
+        """out[M, n_local] (dense, of self.out_dtype) <- epilogue(x . W_local^T)."""
+        if self._gemm is not None:     # a stand-in product (CPU tests): no in-place form
+            out.copy_(self._gemm(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype))
+        elif x.dtype == torch.int8:
+            _native.gemm_i8(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype, out=out)
+        else:
+            _native.gemm_w8(x, self.weight, bias=self.bias, alpha=self.scale, beta=0.0, out_dtype=self.out_dtype, out=out)
+        return out
 
-    def assemble(self, buf, work=None):
-        """[g, M, n_max] blocks -> the [M, N] output a single GPU would have produced."""
-        if work is not None:
-            work.wait()
-        g, M, _ = buf.shape
-        if g == 1:
-            return buf[0]
-        if self.out_features % g == 0:
-            return buf.permute(1, 0, 2).reshape(M, self.out_features)
-        cols = [buf[r, :, :shard_rows(self.out_features, g, r)[1] - shard_rows(self.out_features, g, r)[0]]
-                for r in range(g)]
-        return torch.cat(cols, dim=1)
+    def local_forward(self, x, out=None):
+        """out[:, lo:hi] for activations x [M, K] replicated on every rank: int8 (int8 product) or floating
+        point (the weight-only product on the int8 weight as stored)."""
+        M, n = x.shape[0], self.hi - self.lo
+        if out is None:
+            out = torch.empty((M, n), dtype=self.out_dtype, device=x.device)
+        return self._product(x, out)
 
-    def forward(self, x):
-        buf, work = self.gather_async(self.local_forward(x))
-        return self.assemble(buf, work)
+    def compute_block(self, x, slot=0):
+        """This rank's block computed straight into its slot of the gather buffer (no collective yet)."""
+        M, n = x.shape[0], self.hi - self.lo
+        buf = self._gather_buffer(M, x.device, slot)
+        mine = buf[self.rank, :M * n].view(M, n)
+        if self.gather_dtype == torch.int8:
+            y = self._product(x, torch.empty((M, n), dtype=torch.float32, device=x.device))
+            if self._gemm is not None:
+                mine.copy_(torch.clamp(torch.round(y / self.act_scale.to(y.device)), -128, 127).to(torch.int8))
+            else:
+                if self.act_scale.device != x.device:
+                    self.act_scale = self.act_scale.to(x.device)
+                _native.quantize_rows_given_i8(y, self.act_scale, out=mine)
+        else:
+            self._product(x, mine)
+        return Gathered(buf, M, self.out_features, None)
+
+    def start_gather(self, got):
+        """The in-place all-gather of a computed block (asynchronous: got.wait() before reading other ranks' blocks)."""
+        if self.world > 1:
+            got.work = dist.all_gather_into_tensor(got.buf.view(-1), got.buf[self.rank], group=self.group, async_op=True)
+        return got
+
+    def gather_async(self, x, slot=0):
+        """compute_block + start_gather.  Returns a Gathered (wait() / blocks() / to_dense())."""
+        return self.start_gather(self.compute_block(x, slot))
+
+    def forward(self, x, dense=True):
+        got = self.gather_async(x)
+        return got.to_dense() if dense else got.blocks()
 
     __call__ = forward
 
 
-def run_stack(layers, inputs, assemble=True):
+def run_stack(layers, inputs, dense=True):
     """Apply independent sharded layers, overlapping each all-gather with the next GEMM.
 
     layers: list of ColumnShardedLinear; inputs: one activation tensor per layer.
-    Returns the list of [M, N] outputs (or the raw (buffer, work) pairs with assemble=False).
+    Returns the list of [M, N] outputs (dense=True) or of block lists.
     """
-    pending = []
-    for layer, x in zip(layers, inputs):
-        pending.append((layer,) + layer.gather_async(layer.local_forward(x)))
-    if not assemble:
-        for _, _, work in pending:
-            if work is not None:
-                work.wait()
-        return [buf for _, buf, _ in pending]
-    return [layer.assemble(buf, work) for layer, buf, work in pending]
+    pending = [layer.gather_async(x, slot=i) for i, (layer, x) in enumerate(zip(layers, inputs))]
+    return [p.to_dense() if dense else p.blocks() for p in pending]

@@ -177,9 +177,14 @@ def test_wo_chunker_config1_models(wo, model):
         assert type(layer).__name__ == "Quantizer"
         assert sha(layer.weight.cpu().numpy()) == C1.text(f"{model}/{n}", "sha_q"), n
         assert sha(layer.weight_quant.scales.cpu().numpy()) == C1.text(f"{model}/{n}", "sha_scales"), n
-    # the rewritten model still runs end to end on float inputs, close to the fp32 model
-    q_out = qnet(x)
-    assert q_out.shape == fp_out.shape and torch.isfinite(q_out).all()
+    # The reference flow end to end (quant/Weight_Only/Main.py:40-42: Chunker(model).model, then a forward): the
+    # rewritten model's output on the seeded batch against the reference's own, within 1e-3 of the output's
+    # magnitude (the reference sums in fp32 in a different order; here fp32-accurate MFMA products).
+    np.testing.assert_allclose(fp_out.detach().cpu().numpy(), C1.raw(f"{model}/y_fp"), rtol=1e-4, atol=1e-5)
+    q_out = qnet(x).detach().cpu().numpy()
+    ref = C1.raw(f"{model}/y_quant")
+    assert q_out.shape == ref.shape
+    assert np.abs(q_out - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(q_out - ref).max(), np.abs(ref).max())
 
 
 def test_wa_chunker_simplecnn_golden(wa):
@@ -246,7 +251,8 @@ def test_conv2d_int8_reference_script():
 def test_quantized_state_dict_round_trip_weight_only(tmp_path):
     """state_dict of a weight-only quantized model carries the scales (as each layer's extra state), survives
     torch.save / torch.load(weights_only=True), and a freshly built model that loads it reproduces the
-    outputs bit for bit; a state_dict without the extra state (what the reference writes) still loads."""
+    outputs bit for bit; a state_dict without the extra state (what the reference writes) still loads, but the
+    layers then refuse to run with scales that belong to other weights until the parameters are supplied."""
     import io
     from quantization_amd.quant.Weight_Only.Chunker import Chunker
     from sample_models import SimpleCNN
@@ -270,7 +276,17 @@ def test_quantized_state_dict_round_trip_weight_only(tmp_path):
             assert torch.equal(a.weight, b.weight)
             assert torch.equal(a.weight_quant.scales.reshape(-1).cpu(), b.weight_quant.scales.reshape(-1).cpu())
     legacy = {k: v for k, v in sd2.items() if not k.endswith("_extra_state")}
-    m2.load_state_dict(legacy)                   # strict: the missing extra state is tolerated
+    torch.manual_seed(321)
+    m3 = SimpleCNN().eval()
+    Chunker(m3, None)
+    with pytest.warns(UserWarning, match="no quantization parameters"):
+        m3.load_state_dict(legacy)               # strict: the missing extra state is tolerated ...
+    with pytest.raises(RuntimeError, match="no quantization parameters"):
+        m3(x)                                    # ... but stale scales are never applied to the loaded weights
+    for (n1, a), (n3, c) in zip(m1.named_modules(), m3.named_modules()):
+        if hasattr(a, "weight_quant"):
+            c.set_extra_state(a.get_extra_state())
+    assert torch.equal(m1(x), m3(x))
 
 
 @pytest.mark.gpu
@@ -295,3 +311,41 @@ def test_quantized_state_dict_round_trip_weight_activation():
     x = torch.rand(4, 3, 32, 32)
     y1, y2 = m1(x), m2(x)
     assert y1.dtype == y2.dtype and torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_layer_forward_enqueues_only_and_captures_into_a_graph(wa, wo):
+    """A weight+activation layer whose calibration results live on the GPU, and a weight-only layer kept on the
+    host side of a GPU box (module.cpu(), activations on the GPU): after the first call neither forward reads a
+    device value back nor re-uploads its weight, so both capture into a HIP graph (a synchronising call fails
+    the capture) and replay to the eager results."""
+    dm = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(256, 96)
+    qa = wa.Quantizer.from_float(module=lin, data_metry=dm)
+    qa.scalers = (torch.rand(1, 96) * 1e-2 + 1e-4).cuda()
+    qa.output_zero_point = torch.tensor([3.5]).cuda()
+    qa.bias = qa.bias.detach().cuda()
+    qa = qa.cuda()
+    qo = wo.Quantizer.from_float(module=torch.nn.Linear(256, 64), data_metry=dm)   # weight, bias, scales stay host tensors
+    x = torch.randint(-128, 128, (16, 256), dtype=torch.int32).to(torch.int8).cuda()
+    xf = torch.randn(16, 256).cuda()
+    ya, yo = qa(x), qo(xf)                                   # first calls: the one read of output_zero_point, the uploads
+    uploaded = qo._gpu_cache["weight"][2]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        qa(x), qo(xf)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ga, go = qa(x), qo(xf)
+    assert qo._gpu_cache["weight"][2] is uploaded            # no second upload
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ga, ya) and torch.equal(go, yo)
+    ref = (x.double() @ qa.weight.double().T + qa.bias.double().reshape(1, -1)) * qa.scalers.double() + 3.5
+    assert torch.allclose(ya.double(), ref, rtol=1e-5, atol=1e-5)
+    # replacing the zero point is seen (the cache is keyed on the tensor, not on the layer)
+    qa.output_zero_point = torch.tensor([-1.0]).cuda()
+    assert torch.allclose(qa(x).double(), ref - 4.5, rtol=1e-5, atol=1e-5)

@@ -1,6 +1,7 @@
-"""The multi-GPU path on CPU: two and three processes over gloo run the column-sharded layer
-with a stand-in product (an exact integer matmul written here; the HIP GEMM needs a GPU) and
-must reproduce the unsharded oracle result bit for bit, including a ragged split."""
+"""The multi-GPU path on CPU: 2, 3, 4 and 8 processes over gloo run the column-sharded layer with a
+stand-in product (an exact integer matmul written here; the HIP GEMM needs a GPU) and must reproduce
+the unsharded oracle result bit for bit, including ragged splits, the Llama-3-70B width (28672 output
+channels), ranks that were handed only their own rows, and the bf16 / int8 forms of the gather."""
 import os
 import socket
 import sys
@@ -13,6 +14,8 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 from oracle import oracle_np as O
+
+ACT_SCALE = 37.5
 
 
 def _free_port():
@@ -36,34 +39,48 @@ def _cpu_quantize(w):
     return torch.from_numpy(q), torch.from_numpy(s.reshape(-1))
 
 
-def _worker(rank, world, port, n, tmp):
+def _worker(rank, world, port, n, K, M, tmp):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from quantization_amd.sharded import ColumnShardedLinear, run_stack, shard_rows
         g = torch.Generator().manual_seed(1)                # identical on every rank
-        K, M = 48, 9
         w = torch.randn(n, K, generator=g)
         bias = torch.randn(n, generator=g)
         x = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32).to(torch.int8)
         layer = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize)
         assert (layer.lo, layer.hi) == shard_rows(n, world, rank)
         y = layer(x)
+        y_again = layer(x)                                   # the cached gather buffer, reused
+        blocks = layer(x, dense=False)
+        assert [tuple(b.shape) for b in blocks] == [(M, shard_rows(n, world, r)[1] - shard_rows(n, world, r)[0])
+                                                    for r in range(world)]
+        assert torch.equal(torch.cat(blocks, dim=1), y) and torch.equal(y_again, y)
+        # a rank that was handed only its own rows (how large models are loaded)
+        lo, hi = shard_rows(n, world, rank)
+        own = ColumnShardedLinear.from_float(w[lo:hi].clone(), bias[lo:hi].clone(), gemm=_cpu_gemm, quantize=_cpu_quantize,
+                                             out_features=n)
+        assert torch.equal(own(x), y)
         w2 = torch.randn(n, K, generator=g)
         layer2 = ColumnShardedLinear.from_float(w2, None, gemm=_cpu_gemm, quantize=_cpu_quantize)
         ys = run_stack([layer, layer2], [x, x])
-        if rank == 0:
+        yb = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, gather_dtype=torch.bfloat16)(x)
+        yq = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, gather_dtype=torch.int8,
+                                            act_scale=ACT_SCALE)(x)
+        if rank == world - 1:                                # the last rank: the narrowest shard of a ragged split
             np.savez(tmp, y=y.numpy(), y0=ys[0].numpy(), y1=ys[1].numpy(), w=w.numpy(), w2=w2.numpy(),
-                     bias=bias.numpy(), x=x.numpy())
+                     bias=bias.numpy(), x=x.numpy(), yb=yb.float().numpy(), yq=yq.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 64), (2, 37), (3, 64)])
-def test_column_sharded_linear_equals_unsharded(tmp_path, world, n):
-    out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+@pytest.mark.parametrize("world,n,K,M", [(2, 64, 48, 9), (2, 37, 48, 9), (3, 64, 48, 9), (3, 28672, 32, 5),
+                                         (4, 28672, 32, 5), (8, 28672, 32, 5), (8, 8192, 64, 3)])
+def test_column_sharded_linear_equals_unsharded(tmp_path, world, n, K, M):
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n, K, M, out), nprocs=world, join=True)
     z = np.load(out)
     q, s, _ = O.quantize_channel_sym_int8(z["w"])
     ref = O.wo_linear_forward(z["x"], q, s, z["bias"])
@@ -71,3 +88,15 @@ def test_column_sharded_linear_equals_unsharded(tmp_path, world, n):
     np.testing.assert_array_equal(z["y0"], ref)
     q2, s2, _ = O.quantize_channel_sym_int8(z["w2"])
     np.testing.assert_array_equal(z["y1"], O.wo_linear_forward(z["x"], q2, s2, None))
+    # what the narrower gathers deliver: the fp32 result rounded once to bf16 / requantised with the static scale
+    np.testing.assert_array_equal(z["yb"], O.round_f32_to_bf16(ref))
+    np.testing.assert_array_equal(z["yq"], np.clip(np.rint(ref / np.float32(ACT_SCALE)), -128, 127).astype(np.int8))
+
+
+def test_from_float_checks_the_rows_it_is_given():
+    from quantization_amd.sharded import ColumnShardedLinear
+    w = torch.randn(10, 8)
+    with pytest.raises(RuntimeError, match="expected 12 rows"):
+        ColumnShardedLinear.from_float(w, None, gemm=_cpu_gemm, quantize=_cpu_quantize, out_features=12)
+    with pytest.raises(RuntimeError, match="act_scale"):
+        ColumnShardedLinear.from_float(w, None, gemm=_cpu_gemm, quantize=_cpu_quantize, gather_dtype=torch.int8)
