@@ -283,6 +283,9 @@ def main():
                     "gloo on one GPU moves every gathered byte through the host: give it 256)")
     args = ap.parse_args()
 
+    if os.environ.get("MIQ_BENCH_WATCHDOG"):   # rehearsal aid: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MIQ_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -365,6 +368,8 @@ def main():
                 e1.record()
                 events.append((e0, e1))
             pending[slot] = layer.start_gather(got)
+            if backend != "nccl":      # rehearsal backends run their collectives on host threads: one at a time
+                pending[slot].wait()
         for p in pending:
             if p is not None:
                 p.wait()

@@ -819,9 +819,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const int* __restric
 // kDepth rounds ahead; tiles past K load as zeros and add nothing).  The eight partial sums meet
 // in LDS, and one thread per output finishes the sum and applies the epilogue.
 // ---------------------------------------------------------------------------------------
-template <int MT, int WN, int OUT>
+template <int MT, int WN, int OUT, int DEPTH = 4, bool NT = false>
 __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
-    constexpr int kWaves = 8, kDepth = 4;
+    constexpr int kWaves = 8, kDepth = DEPTH;
     __shared__ int red[kWaves * MT * WN * 256];
 
     const int lane = threadIdx.x & 63;
@@ -846,8 +846,11 @@ __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
     struct Slot {
         v4i w[2][WN], a[2][MT];   // [k-step][fragment]
     };
-    auto load16 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t base, int k) -> v4i {
+    // (NT: the weight is read once by one workgroup, so its loads are marked non-temporal and do not displace
+    // the activations, which every workgroup re-reads, from the caches)
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t base, int k, bool weight) -> v4i {
         const uint32_t off = (base != kOob && k + cb < g.K) ? base + k : kOob;
+        if (NT && weight) return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2));
         return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     };
     auto fill = [&](Slot& s, int kt) {
@@ -855,9 +858,9 @@ __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
         for (int ks = 0; ks < 2; ++ks) {
             const int k = kt * kTileK + ks * 64;
 #pragma unroll
-            for (int j = 0; j < WN; ++j) s.w[ks][j] = load16(rw, wbase[j], k);
+            for (int j = 0; j < WN; ++j) s.w[ks][j] = load16(rw, wbase[j], k, true);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) s.a[ks][i] = load16(ra, abase[i], k);
+            for (int i = 0; i < MT; ++i) s.a[ks][i] = load16(ra, abase[i], k, false);
         }
     };
 
@@ -917,6 +920,23 @@ __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
 
 template <int MT, int OUT>
 int launch_skinny(const GemmArgs& g, hipStream_t st) {
+#ifndef MIQ_NO_DEV_SWITCHES
+    // developer sweep: MIQ_SKINNY = "<channel groups per workgroup><K-tiles in flight per wave><n|c>", e.g. "28n"
+    if (const char* sk = dev_switch("MIQ_SKINNY")) {
+        if constexpr (OUT == kOutF32) {
+            const int wn = sk[0] - '0', depth = sk[1] - '0';
+            const bool nt = sk[2] == 'n';
+#define MIQ_SK(W, D)                                                                                              \
+    if (wn == W && depth == D) {                                                                                  \
+        if (nt) gemm_i8_skinny_kernel<MT, W, OUT, D, true><<<static_cast<int>(ceil_div(g.N, 16 * W)), 512, 0, st>>>(g);  \
+        else gemm_i8_skinny_kernel<MT, W, OUT, D, false><<<static_cast<int>(ceil_div(g.N, 16 * W)), 512, 0, st>>>(g);    \
+        return check_launch("gemm_i8_skinny_kernel");                                                             \
+    }
+            MIQ_SK(1, 2) MIQ_SK(1, 4) MIQ_SK(1, 8) MIQ_SK(2, 2) MIQ_SK(2, 4) MIQ_SK(2, 8) MIQ_SK(4, 2) MIQ_SK(4, 4)
+#undef MIQ_SK
+        }
+    }
+#endif
     // 32 channels per workgroup when that still gives every CU a workgroup, else 16.
     if (ceil_div(g.N, 32) >= 256) {
         gemm_i8_skinny_kernel<MT, 2, OUT><<<static_cast<int>(ceil_div(g.N, 32)), 512, 0, st>>>(g);
