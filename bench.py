@@ -218,8 +218,8 @@ def config5(N_, dev, world, rank, dist, m_list=(256, 2048, 8192)):
                 layer.gather_async(x).wait()
                 torch.cuda.synchronize()
                 both.append((time.perf_counter() - t0) * 1e3)
-            t = torch.tensor([gemm_ms, sorted(gather)[len(gather) // 2], sorted(both)[len(both) // 2]], device=dev,
-                             dtype=torch.float64)
+            t = torch.tensor([gemm_ms, sorted(gather)[len(gather) // 2], sorted(both)[len(both) // 2]],
+                             device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gemm_ms, gather_ms, layer_ms = (float(v) for v in t.tolist())
@@ -283,10 +283,14 @@ def main():
                     "gloo on one GPU moves every gathered byte through the host: give it 256)")
     args = ap.parse_args()
 
-    if os.environ.get("MIQ_BENCH_WATCHDOG"):   # rehearsal aid: dump every thread's stack and exit after that many seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["MIQ_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # A multi-rank run that stops making progress (a collective that never completes) must end loudly, not hang:
+    # after MIQ_BENCH_WATCHDOG seconds (default 900 with more than one rank) every thread's stack is dumped and
+    # the process exits.
+    watchdog = int(os.environ.get("MIQ_BENCH_WATCHDOG", "900" if world > 1 else "0"))
+    if watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -368,8 +372,6 @@ def main():
                 e1.record()
                 events.append((e0, e1))
             pending[slot] = layer.start_gather(got)
-            if backend != "nccl":      # rehearsal backends run their collectives on host threads: one at a time
-                pending[slot].wait()
         for p in pending:
             if p is not None:
                 p.wait()
@@ -386,7 +388,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed

@@ -175,7 +175,15 @@ class ColumnShardedLinear:
     def start_gather(self, got):
         """The in-place all-gather of a computed block (asynchronous: got.wait() before reading other ranks' blocks)."""
         if self.world > 1:
-            got.work = dist.all_gather_into_tensor(got.buf.view(-1), got.buf[self.rank], group=self.group, async_op=True)
+            if got.buf.is_cuda and dist.get_backend(self.group) != "nccl":
+                # A host backend (gloo: rehearsals with every rank on one GPU) is handed host tensors: its own
+                # staging of device tensors stalled intermittently on a shared GPU (measured).  Synchronous.
+                send = got.buf[self.rank].cpu()
+                recv = torch.empty(got.buf.shape, dtype=got.buf.dtype)
+                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+                got.buf.copy_(recv)
+            else:
+                got.work = dist.all_gather_into_tensor(got.buf.view(-1), got.buf[self.rank], group=self.group, async_op=True)
         return got
 
     def gather_async(self, x, slot=0):

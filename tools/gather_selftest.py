@@ -75,6 +75,23 @@ for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32), ("i8", torch.
     t = torch.tensor([1.0], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     say(f"6 in-place gathers of [{world}, 2048*2048] {name} ok")
+# the bench's step: a 2048^3 GEMM into the rank's slot, then the in-place gather, no device-wide wait in between
+mode = os.environ.get("MIQ_SELFTEST_MODE", "inplace")
+g = torch.Generator(device=dev).manual_seed(2)
+w = torch.randn(2048, 2048, generator=g, device=dev)
+x = torch.randint(-128, 128, (2048, 2048), generator=g, dtype=torch.int32, device=dev).to(torch.int8)
+for gd in (torch.bfloat16, torch.float32):
+    layer = ColumnShardedLinear.from_float(w, None, out_dtype=gd, out_features=2048 * world)
+    for i in range(8):
+        got = layer.compute_block(x, i & 1)
+        if mode == "inplace":
+            layer.start_gather(got).wait()
+        else:
+            src = got.buf[rank].clone()
+            dist.all_gather_into_tensor(got.buf.view(-1), src, async_op=True).wait()
+        print(f"rank {rank}: {gd} step {i} ({mode})", flush=True)
+    torch.cuda.synchronize()
+    dist.barrier()
 dist.barrier()
 say("selftest ok")
 faulthandler.cancel_dump_traceback_later()
