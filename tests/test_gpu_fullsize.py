@@ -124,8 +124,11 @@ def test_gemm_full_size_checksums(N, M, Nn, K):
     assert torch.equal(yb, y.to(torch.bfloat16))   # every element: the fp32 result rounded once (round-half-even)
 
 
+# every distinct convolution of ResNet-18 (eleven shapes) at batch 256
 @pytest.mark.parametrize("C,H,Co,k,s,p", [(64, 56, 64, 3, 1, 1), (3, 224, 64, 7, 2, 3), (128, 28, 256, 3, 2, 1),
-                                          (256, 14, 256, 3, 1, 1), (512, 7, 512, 3, 1, 1), (64, 56, 128, 1, 2, 0)])
+                                          (256, 14, 256, 3, 1, 1), (512, 7, 512, 3, 1, 1), (64, 56, 128, 1, 2, 0),
+                                          (64, 56, 128, 3, 2, 1), (128, 28, 128, 3, 1, 1), (256, 14, 512, 3, 2, 1),
+                                          (128, 28, 256, 1, 2, 0), (256, 14, 512, 1, 2, 0)])
 def test_conv_resnet18_batch256(N, C, H, Co, k, s, p):
     B = 256
     x, w = rand_i8((B, C, H, H), C + H), rand_i8((Co, C, k, k), Co + k)
