@@ -593,6 +593,271 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
 }
 
 // ---------------------------------------------------------------------------------------
+// 256 pixels x 256 output channels per workgroup, software-pipelined: the int8 GEMM's four-phase schedule
+// (quantization_amd/csrc/miq_gemm_i8.hip, gemm_i8_256_kernel) with the convolution's addressing on the pixel
+// side.  Layers with at least 256 output channels and enough tiles to fill the chip run here: their K axis
+// (KH * KW * Cin >= 1152) is long enough for a pipeline to pay, and the double-buffered kernel above waits a
+// full LDS-DMA round trip per K-tile.
+//
+// 8 waves as 2 (pixels) x 4 (channels); a wave owns 128 x 64 outputs as four 64 x 32 quadrants.  A 128-byte
+// K-tile lives in LDS as four 16 KiB half-tiles P0 P1 (pixels 0-127 / 128-255) and W0 W1 (channels likewise);
+// two K-tile buffers.  Per K-tile four phases of 16 MFMAs, each LOAD (fragment reads, one half-tile of LDS-DMA
+// for a later K-tile, a counted vmcnt) | barrier | MFMA | barrier, waves 4-7 one barrier behind waves 0-3:
+//   P1: read W0(t)   | DMA W1(t+1) | MFMA (P0, W0)      P3: read P1(t)   | DMA P0(t+2) | MFMA (P1, W1)
+//   P2: read W1(t)   | DMA P1(t+1) | MFMA (P0, W1)      P4: read P0(t+1) | DMA W0(t+2) | MFMA (P1, W0)
+// vmcnt(8) after a phase's issue = "the half-tile issued four phases ago has landed"; a half-tile is read no
+// earlier than one phase after that wait and re-staged three phases after its last read.
+// Pixels are the MFMA's first operand: a lane ends with four consecutive pixels of one channel (NCHW stores).
+// ---------------------------------------------------------------------------------------
+#define MIQ_CONV_BARRIER()                  \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();       \
+        asm volatile("" ::: "memory");      \
+    } while (0)
+#define MIQ_CONV_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+
+template <int OUT, bool STREAM>
+__global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
+    constexpr int kHalf = 128 * kTileK;   // one half-tile: 128 rows x 128 B
+    constexpr int kBuf = 4 * kHalf;       // P0 P1 W0 W1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nchunks = g.Kp / kChunk;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+
+    // Staging: a wave-instruction moves 8 rows x 128 B; a wave issues two per half-tile (row groups `wave` and
+    // `wave + 8`).  The chunk slot a lane fills is fixed by the swizzle (the same for both of its rows).
+    const int srow = wave * 8 + (lane >> 3);
+    const int cslot = (lane & 7) ^ ((srow >> 1) & 7);
+    uint32_t pix[2][2], wbase[2][2];   // [half][piece]: pixel base in xp / weight row offset at k = 0
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + h * 128 + srow + i * 64;
+            if (m < g.M) {
+                const int b = m / g.HoWo, p = m % g.HoWo;
+                pix[h][i] = static_cast<uint32_t>(b) * g.img_stride + (p / g.Wo) * g.sy + (p % g.Wo) * g.sx;
+            } else {
+                pix[h][i] = kOob;
+            }
+            const int n = n0 + h * 128 + srow + i * 64;
+            wbase[h][i] = n < g.Cout ? static_cast<uint32_t>(n) * g.Kp + cslot * kChunk : kOob;
+        }
+    auto stage_pix = [&](char* dst, const uint32_t (&base)[2], int kt) {
+        // chunk q of the K axis = filter row q / cps, byte (q % cps) * 16 of that row's run
+        const int q = kt * kChunksPerRow + cslot;
+        const int kh = g.cps == 1 ? q : static_cast<int>(__umulhi(static_cast<uint32_t>(q), g.cps_magic));
+        const uint32_t koff = static_cast<uint32_t>(kh * g.row_stride + (q - kh * g.cps) * kChunk);
+        const bool ok = q < nchunks;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t off = (ok && base[i] != kOob) ? base[i] + koff : kOob;
+            dma16(rx, dst + (wave + 8 * i) * (8 * kTileK), off);
+        }
+    };
+    auto stage_w = [&](char* dst, const uint32_t (&base)[2], int kt) {
+        const int k = kt * kTileK;
+        const bool ok = k + cslot * kChunk < g.Kp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t off = (ok && base[i] != kOob) ? base[i] + k : kOob;
+            dma16(rw, dst + (wave + 8 * i) * (8 * kTileK), off);
+        }
+    };
+
+    v4i acc[2][2][4][2];   // [pixel half][channel half][pixel fragment][channel fragment]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = v4i{0, 0, 0, 0};
+
+    const int nt = (g.Kp + kTileK - 1) / kTileK;
+    const int lo[2] = {frag_lane_offset(lane, 0), frag_lane_offset(lane, 1)};
+    const int p_frag = wm * 64 * kTileK;   // this wave's rows inside a pixel half-tile
+    const int w_frag = wn * 32 * kTileK;   // and inside a weight half-tile
+
+    // Prologue: all of tile 0 plus P0/W0 of tile 1; wait for P0(0), W0(0) only.
+    stage_pix(smem + 0 * kHalf, pix[0], 0);
+    stage_w(smem + 2 * kHalf, wbase[0], 0);
+    stage_w(smem + 3 * kHalf, wbase[1], 0);
+    stage_pix(smem + 1 * kHalf, pix[1], 0);
+    stage_pix(smem + kBuf + 0 * kHalf, pix[0], 1);
+    stage_w(smem + kBuf + 2 * kHalf, wbase[0], 1);
+    MIQ_CONV_WAIT_DMA();
+    MIQ_CONV_BARRIER();
+    if (wm == 1) MIQ_CONV_BARRIER();   // waves 4-7 run one barrier behind
+
+    v4i pf[2][4] = {}, pf2[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [k-step][fragment]
+    auto read_w = [&](v4i (&wf)[2][2], const char* half) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[ks][j] = lds_read16(half + w_frag + j * 16 * kTileK + lo[ks]);
+    };
+    auto read_p = [&](v4i (&f)[2][4], const char* half) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[ks][i] = lds_read16(half + p_frag + i * 16 * kTileK + lo[ks]);
+    };
+    auto mma = [&](v4i (&c)[4][2], const v4i (&f)[2][4], const v4i (&wf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks][i], wf[ks][j], c[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    read_p(pf, smem + 0 * kHalf);   // P0(0)
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * kBuf;
+        char* nxt = smem + ((t + 1) & 1) * kBuf;
+
+        read_w(wf0, cur + 2 * kHalf);
+        stage_w(nxt + 3 * kHalf, wbase[1], t + 1);
+        MIQ_CONV_WAIT_DMA();   // W1(t) has landed
+        MIQ_CONV_BARRIER();
+        mma(acc[0][0], pf, wf0);
+        MIQ_CONV_BARRIER();
+
+        read_w(wf1, cur + 3 * kHalf);
+        stage_pix(nxt + 1 * kHalf, pix[1], t + 1);
+        MIQ_CONV_WAIT_DMA();   // P1(t)
+        MIQ_CONV_BARRIER();
+        mma(acc[0][1], pf, wf1);
+        MIQ_CONV_BARRIER();
+
+        read_p(pf2, cur + 1 * kHalf);
+        stage_pix(cur + 0 * kHalf, pix[0], t + 2);
+        MIQ_CONV_WAIT_DMA();   // P0(t+1)
+        MIQ_CONV_BARRIER();
+        mma(acc[1][1], pf2, wf1);
+        MIQ_CONV_BARRIER();
+
+        read_p(pf, nxt + 0 * kHalf);   // P0(t+1): retired by the wait one phase ago
+        stage_w(cur + 2 * kHalf, wbase[0], t + 2);
+        MIQ_CONV_WAIT_DMA();   // W0(t+1)
+        MIQ_CONV_BARRIER();
+        mma(acc[1][0], pf2, wf0);
+        MIQ_CONV_BARRIER();
+    }
+    if (wm == 0) MIQ_CONV_BARRIER();   // every wave executes the same number of barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
+
+    // Epilogue.  D[r][c] of a fragment: r = 4*(lane>>4) + reg -> pixel, c = lane&15 -> output channel.
+    const bool vec_ok = (g.HoWo & 3) == 0;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane & 15);
+            float al = 1.f, bi = 0.f;
+            if constexpr (OUT != kOutI32) {
+                if (n < g.Cout) {
+                    al = g.alpha[n];
+                    if (g.bias) bi = g.bias[n];
+                }
+            }
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm) {
+                const int mq = m0 + qm * 128 + wm * 64;
+                if constexpr (OUT == kOutBF16) {
+                    if (g.wide16) {   // HoWo % 8 == 0 and a 16-byte aligned output: eight pixels share an image
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            uint2 p[2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const v4i a = acc[qm][qn][i + h][j];
+                                p[h] = pack4_bf16(dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                                  dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
+                            }
+                            const v4i v = pair_rows_bf16(p[0], p[1]);
+                            const int m = mq + i * 16 + paired_offset(lane);
+                            if (m >= g.M || n >= g.Cout) continue;
+                            const int b = m / g.HoWo, px = m % g.HoWo;
+                            v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) +
+                                                            (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + px);
+                            if constexpr (STREAM) {
+                                __builtin_nontemporal_store(v, o);
+                            } else {
+                                *o = v;
+                            }
+                        }
+                        continue;
+                    }
+                }
+                if (n >= g.Cout) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mq + i * 16 + (lane >> 4) * 4;
+                    if (m >= g.M) continue;
+                    const v4i a = acc[qm][qn][i][j];
+                    if (vec_ok) {   // m % 4 == 0 and HoWo % 4 == 0: the four pixels share an image
+                        const int b = m / g.HoWo, p = m % g.HoWo;
+                        const size_t idx = (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + p;
+                        if constexpr (OUT == kOutI32) {
+                            v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
+                            if constexpr (STREAM) {
+                                __builtin_nontemporal_store(a, o);
+                            } else {
+                                *o = a;
+                            }
+                        } else if constexpr (OUT == kOutF32) {
+                            const v4f y{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                        dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta)};
+                            v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
+                            if constexpr (STREAM) {
+                                __builtin_nontemporal_store(y, o);
+                            } else {
+                                *o = y;
+                            }
+                        } else {
+                            *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) =
+                                pack4_bf16(dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                           dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int me = m + e;
+                            if (me >= g.M) break;
+                            const int b = me / g.HoWo, p = me % g.HoWo;
+                            const size_t idx = (static_cast<size_t>(b) * g.Cout + n) * g.HoWo + p;
+                            if constexpr (OUT == kOutI32) {
+                                static_cast<int*>(g.out)[idx] = a[e];
+                            } else if constexpr (OUT == kOutF32) {
+                                static_cast<float*>(g.out)[idx] = dequant1(a[e], bi, al, g.beta);
+                            } else {
+                                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(dequant1(a[e], bi, al, g.beta));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------
 // 3 x 3, stride 1: the convolution as nine shifted GEMMs over a pixel patch that stays in LDS.
 //
 // The padded copy is kept in chunk planes, xp[c / 16][image][padded row][padded column][c % 16], rows at a
@@ -858,6 +1123,18 @@ int launch_tile(ConvArgs g, hipStream_t st) {
 }
 
 template <int OUT>
+int launch_pipe(ConvArgs g, hipStream_t st) {
+    g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
+    g.tiles_n = static_cast<int>(ceil_div(g.Cout, 256));
+    constexpr int lds = 2 * 4 * 128 * kTileK;
+    auto kern = conv_i8_pipe_kernel<OUT, false>;
+    if (g.stream_out) kern = conv_i8_pipe_kernel<OUT, true>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    kern<<<g.tiles_m * g.tiles_n, 512, lds, st>>>(g);
+    return check_launch("conv_i8_pipe_kernel");
+}
+
+template <int OUT>
 int launch(const ConvArgs& g, hipStream_t st) {
     // Largest tile that still gives the 256 CUs enough workgroups; BN follows Cout.
     auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
@@ -868,13 +1145,14 @@ int launch(const ConvArgs& g, hipStream_t st) {
             case 'c': return launch_tile<256, 64, 4, 2, OUT>(g, st);
             case 'd': return launch_tile<128, 128, 2, 2, OUT>(g, st);
             case 'e': return launch_tile<128, 64, 2, 2, OUT>(g, st);
+            case 'p': return launch_pipe<OUT>(g, st);
             default: break;
         }
     }
     // Measured on the ResNet-18 layers at batch 256 (MIQ_CONV_TILE sweep): 256 x 256 wins once it gives most
     // CUs a tile (196 tiles: 55 vs 61-66 us on 256->256 14x14); up to 128 output channels the 128 x 64 tile
     // (three workgroups per CU) beats 256 x 128 and 128 x 128 (69 vs 81 / 76 us on 64->128 3x3/2).
-    if (g.Cout > 128 && tiles(256, 256) >= 160) return launch_tile<256, 256, 2, 4, OUT>(g, st);
+    if (g.Cout > 128 && tiles(256, 256) >= 160) return launch_pipe<OUT>(g, st);
     if (g.Cout > 128) return launch_tile<128, 128, 2, 2, OUT>(g, st);
     if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
     return launch_tile<128, 64, 2, 2, OUT>(g, st);
