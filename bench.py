@@ -191,6 +191,34 @@ def conv_int8(N_, dev):
         del x, w, outs
     res["stack"] = {"layers": 20, "total_ms": round(total_ms, 4), "TOPS": round(total_ops / (total_ms * 1e-3) / 1e12, 1),
                     "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms)}
+    # The same twenty layers as an int8 pipeline hands them over: channels-last int8 in (border present), int8 out
+    # requantised in the epilogue, written with the next layer's border (miq_conv2d_i8_nhwc): one kernel per layer, no
+    # re-layout.  The first layer's three input channels are carried as four (a zero channel).
+    cl_ms, cl_ops, cl_bytes = 0.0, 0.0, 0.0
+    for C, H, Co, k, s, p, times in RESNET18_CONVS:
+        Cc = 4 if C == 3 else C
+        x = torch.zeros(B, H + 2 * p, H + 2 * p, Cc, dtype=torch.int8, device=dev)
+        x[:, p:H + p, p:H + p, :C] = torch.randint(-128, 128, (B, H, H, C), dtype=torch.int32, device=dev).to(torch.int8)
+        w = torch.zeros(Co, Cc, k, k, dtype=torch.int8, device=dev)
+        w[:, :C] = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device=dev).to(torch.int8)
+        wp = N_.conv2d_i8_pack_weight(w)
+        alpha = torch.rand(Co, device=dev) * 1e-4
+        Ho = (H + 2 * p - k) // s + 1
+        outs = [torch.zeros(B, Ho + 2, Ho + 2, Co, dtype=torch.int8, device=dev) for _ in range(3)]
+        it = [0]
+
+        def step_cl():
+            N_.conv2d_i8_nhwc(x, wp, w.shape, s, p, alpha=alpha, out_dtype=torch.int8, out_pad=1, out=outs[it[0] % 3])
+            it[0] += 1
+        ms = median_ms(step_cl, 30, 30)
+        cl_ms += ms * times
+        cl_ops += 2.0 * B * Co * Ho * Ho * C * k * k * times
+        cl_bytes += (x.numel() + w.numel() + B * Ho * Ho * Co) * times
+        del x, w, wp, outs
+    res["stack_channels_last_int8"] = {
+        "layers": 20, "total_ms": round(cl_ms, 4), "TOPS": round(cl_ops / (cl_ms * 1e-3) / 1e12, 1),
+        "images_per_s": round(B / (cl_ms * 1e-3)), "roofline": mfma_roofline(cl_ops, cl_ms),
+        "hbm_GBps_on_algorithmic_bytes": round(cl_bytes / (cl_ms * 1e-3) / 1e9, 1)}
     return res
 
 

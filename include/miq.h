@@ -199,6 +199,25 @@ int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int6
                   const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* int8 Conv2d on channels-last activations: the form in which a stack of int8 layers hands its activations from
+ * one layer to the next without any re-layout pass (miq_conv2d_i8 above spends about a quarter of a ResNet-18 stack
+ * turning NCHW into this form, layer by layer).  Same arithmetic and epilogue as miq_conv2d_i8, which replaces
+ * conv2d_int8 (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:81-114) and the Conv2d forward of the Python layers; the
+ * channels-last layout and the int8 output have no counterpart in the reference, whose kernel is NCHW only.
+ *   x:   int8 [B][H + 2*pad][W + 2*pad][Cin], the border already present and zero, Cin % 4 == 0, 16-byte aligned.
+ *   wp:  the OIHW weight re-laid once by miq_conv2d_i8_pack_weight (miq_conv2d_i8_packed_weight_bytes bytes).
+ *   out: [B][Ho + 2*out_pad][Wo + 2*out_pad][Cout], Cout % 4 == 0; only the Ho x Wo interior is written, so a buffer
+ *        whose border was zeroed once serves as the next layer's x as it is.  out_dtype MIQ_I32 (raw sums), MIQ_F32 /
+ *        MIQ_BF16 ((acc + bias[c]) * alpha[c] + beta), or MIQ_I8: that value requantised, clamp(rint(.), -128, 127),
+ *        round-half-even: the per-tensor form of Qop.quantize (quant/Weight_Only/Qop.py:154-157) with the next
+ *        layer's activation scale folded into alpha.
+ * No workspace, no allocation; dilation 1, groups 1, one stride and one padding for both axes. */
+size_t miq_conv2d_i8_packed_weight_bytes(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW);
+int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int8_t* wp, void* stream);
+int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                       int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias, const float* alpha,
+                       float beta, void* out, int out_dtype, int64_t out_pad, void* stream);
+
 /* 2-D pooling with an int8 result, NCHW: what QuantizedMaxPool2d / QuantizedAvgPool2d compute
  * (quant/Weight_Activation/Quantizer.py:122-130: nn.MaxPool2d / nn.AvgPool2d on x.float(), then
  * .to(torch.int8)), in one pass over x.
@@ -210,7 +229,7 @@ int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int6
  * forwards (quant/Weight_Activation/Chunker.py:75-77).  The cast to int8 truncates toward zero
  * and wraps modulo 256 as the host's cast does (200.0 -> -56); NaN and |v| >= 2^31 give 0.
  */
-#define MIQ_I8 4 /* inputs only */
+#define MIQ_I8 4 /* inputs; as an output only of miq_conv2d_i8_nhwc */
 #define MIQ_POOL_MAX 0
 #define MIQ_POOL_AVG 1
 int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw,

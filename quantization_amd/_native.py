@@ -19,6 +19,7 @@ MIQ_W_NK, MIQ_W_KN = 0, 1
 
 _FLOAT_CODES = {torch.float32: MIQ_F32, torch.float16: MIQ_F16, torch.bfloat16: MIQ_BF16}
 _OUT_CODES = {torch.float32: MIQ_F32, torch.bfloat16: MIQ_BF16, torch.int32: MIQ_I32}
+_OUT_CODES_CL = {**_OUT_CODES, torch.int8: MIQ_I8}
 
 _i64 = ctypes.c_int64
 _p = ctypes.c_void_p
@@ -46,6 +47,9 @@ SYMBOLS = {
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_conv2d_i8_packed_weight_bytes": (_size, [_i64] * 4),
+    "miq_conv2d_i8_pack_weight": (_int, [_p] + [_i64] * 4 + [_p, _p]),
+    "miq_conv2d_i8_nhwc": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _i64, _p]),
     "miq_pool2d_to_i8": (_int, [_p, _int] + [_i64] * 4 + [_int] * 7 + [_p, _p]),
     "miq_tensor_minmax_workspace": (_size, [_i64]),
     "miq_tensor_minmax": (_int, [_p, _int, _i64, _p, _p, _size, _p]),
@@ -422,6 +426,57 @@ def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
     with _on(x.device):
         _check(L.miq_conv2d_i8(_ptr(x), _ptr(w), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
                                float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+    return out
+
+
+def conv2d_i8_pack_weight(w):
+    """OIHW int8 weight -> the packed form miq_conv2d_i8_nhwc stages from (done once per layer)."""
+    require_device(w, "kernel")
+    if w.dtype != torch.int8 or w.dim() != 4:
+        raise RuntimeError("kernel must be a 4-D int8 tensor (OIHW)")
+    Co, Ci, KH, KW = w.shape
+    L = lib()
+    wp = torch.empty(max(L.miq_conv2d_i8_packed_weight_bytes(Ci, Co, KH, KW), 16), dtype=torch.int8, device=w.device)
+    with _on(w.device):
+        _check(L.miq_conv2d_i8_pack_weight(_ptr(w), Ci, Co, KH, KW, _ptr(wp), _stream()))
+    return wp
+
+
+def conv2d_i8_nhwc(x, wp, kernel_shape, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.int8,
+                   out_pad=0, out=None):
+    """int8 Conv2d on channels-last activations, no re-layout pass.
+
+    x: int8 [B, H + 2*padding, W + 2*padding, Cin] whose border is present and zero; wp: conv2d_i8_pack_weight(w);
+    kernel_shape = w.shape (Cout, Cin, KH, KW).  Returns / fills out [B, Ho + 2*out_pad, Wo + 2*out_pad, Cout]: only the
+    interior is written (a fresh buffer is zero-filled here; pass `out` to reuse one whose border is already zero).
+    out_dtype int8 requantises: clamp(rint((acc + bias) * alpha + beta), -128, 127)."""
+    require_device(x, "input")
+    require_device(wp, "packed kernel")
+    if x.dtype != torch.int8 or wp.dtype != torch.int8 or x.dim() != 4:
+        raise RuntimeError("input must be a 4-D int8 tensor [B, Hp, Wp, Cin] and the packed kernel int8")
+    Co, Ci, KH, KW = (int(v) for v in kernel_shape)
+    stride, padding, out_pad = int(stride), int(padding), int(out_pad)
+    B, Hp, Wp, C = x.shape
+    H, W = Hp - 2 * padding, Wp - 2 * padding
+    if C != Ci or H <= 0 or W <= 0 or stride < 1 or padding < 0 or out_pad < 0:
+        raise RuntimeError(f"input {tuple(x.shape)} does not match the kernel {tuple(kernel_shape)} / padding {padding}")
+    if Hp < KH or Wp < KW:
+        raise RuntimeError("kernel larger than the padded input")
+    if out_dtype not in _OUT_CODES_CL:
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    Ho, Wo = (Hp - KH) // stride + 1, (Wp - KW) // stride + 1
+    bias = _f32_vec(bias, Co, "bias", x.device)
+    alpha = _f32_vec(alpha, Co, "alpha", x.device)
+    shape = (B, Ho + 2 * out_pad, Wo + 2 * out_pad, Co)
+    if out is None:
+        out = (torch.zeros if out_pad else torch.empty)(shape, dtype=out_dtype, device=x.device)
+    else:
+        require_device(out, "out")
+        if tuple(out.shape) != shape or out.dtype != out_dtype or out.device != x.device:
+            raise RuntimeError("out has the wrong shape, dtype or device")
+    with _on(x.device):
+        _check(lib().miq_conv2d_i8_nhwc(_ptr(x), _ptr(wp), B, Ci, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
+                                        float(beta), _ptr(out), _OUT_CODES_CL[out_dtype], out_pad, _stream()))
     return out
 
 

@@ -49,11 +49,11 @@ constexpr int kWStageBytes = 9 * 4 * 64 * kChunk;       // 36 KiB: [tap][chunk][
 constexpr int kPlanarStage = kPatchBytes + kWStageBytes;
 
 bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
-               int64_t pad, ConvGeom& g) {
+               int64_t pad, ConvGeom& g, bool relayout = true) {   // relayout = false: the caller's channels-last form is staged as it is
     g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
     const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
-    if (KH == 1 && KW == 1 && pad == 0 && stride > 1 && H * W < (1ll << 30) && !(ss && ss[0] == '0')) {
+    if (relayout && KH == 1 && KW == 1 && pad == 0 && stride > 1 && H * W < (1ll << 30) && !(ss && ss[0] == '0')) {
         g.sub = stride;
         g.H = H = (H - 1) / stride + 1;
         g.W = W = (W - 1) / stride + 1;
@@ -77,7 +77,7 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     g.ptot = B * g.Hp * g.pitch;
     const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
     g.planar = false;
-    if (KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
+    if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
         !(sw && sw[0] == '0')) {
         int64_t rows = 0;
         for (int64_t p0 = 0; p0 < g.Ho * g.Wo; p0 += kTM) {
@@ -386,7 +386,32 @@ struct ConvArgs {
     int stream_out;           // 1: nontemporal 16-byte output stores (outputs far larger than the 256 MiB cache)
     int wide16;               // bf16 output: eight pixels per 16-byte store (HoWo % 8 == 0, 16-byte aligned output)
     int tiles_m, tiles_n;
+    // channels-last output (CL kernels): element strides of out[b][y + border][x + border][channel]
+    int o_img, o_row, o_pix, o_off;
 };
+
+// Channels-last epilogue shared by the CL kernels: a lane holds four consecutive channels n .. n+3 (n % 4 == 0,
+// Cout % 4 == 0) of output pixel m and stores them as one vector of the output type.
+template <int OUT>
+__device__ __forceinline__ void store_pixel_channels(const ConvArgs& g, int m, int n, const v4i& a, const float (&al)[4],
+                                                     const float (&bi)[4]) {
+    const int b = m / g.HoWo, p = m - b * g.HoWo;
+    const int y = p / g.Wo, x = p - y * g.Wo;
+    const size_t idx = static_cast<size_t>(b) * g.o_img + static_cast<size_t>(y) * g.o_row + x * g.o_pix + g.o_off + n;
+    if constexpr (OUT == kOutI32) {
+        *reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx) = a;
+    } else {
+        const float y0 = dequant1(a[0], bi[0], al[0], g.beta), y1 = dequant1(a[1], bi[1], al[1], g.beta),
+                    y2 = dequant1(a[2], bi[2], al[2], g.beta), y3 = dequant1(a[3], bi[3], al[3], g.beta);
+        if constexpr (OUT == kOutF32) {
+            *reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx) = v4f{y0, y1, y2, y3};
+        } else if constexpr (OUT == kOutBF16) {
+            *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) = pack4_bf16(y0, y1, y2, y3);
+        } else {
+            *reinterpret_cast<uint32_t*>(static_cast<int8_t*>(g.out) + idx) = requant4_i8(y0, y1, y2, y3);
+        }
+    }
+}
 
 template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* tile, int row0, int nrows, int K, int kt,
@@ -408,7 +433,9 @@ __device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* ti
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool STREAM>
+// CL = channels-last output: the weight fragment is then the MFMA's first operand, so that a lane ends with four
+// consecutive channels of one pixel (store_pixel_channels) instead of four consecutive pixels of one channel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool STREAM, bool CL = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -494,9 +521,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
+    }
+
+    if constexpr (CL) {   // D[r][c]: r = 4*(lane>>4) + reg -> channel, c = lane&15 -> pixel
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+            float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (OUT != kOutI32) {
+                if (n < g.Cout) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        al[e] = g.alpha[n + e];
+                        if (g.bias) bi[e] = g.bias[n + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + (lane & 15);
+                if (m < g.M && n < g.Cout) store_pixel_channels<OUT>(g, m, n, acc[i][j], al, bi);
+            }
+        }
+        return;
     }
 
     // Epilogue.  D[i][j]: i = 4*(lane>>4) + reg -> pixel, j = lane&15 -> output channel.
@@ -617,7 +668,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     } while (0)
 #define MIQ_CONV_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
-template <int OUT, bool STREAM>
+template <int OUT, bool STREAM, bool CL = false>
 __global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
     constexpr int kHalf = 128 * kTileK;   // one half-tile: 128 rows x 128 B
     constexpr int kBuf = 4 * kHalf;       // P0 P1 W0 W1
@@ -723,7 +774,8 @@ __global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks][i], wf[ks][j], c[i][j], 0, 0, 0);
+                    c[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[ks][j], f[ks][i], c[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_i32_16x16x64_i8(f[ks][i], wf[ks][j], c[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -762,6 +814,33 @@ __global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
     }
     if (wm == 0) MIQ_CONV_BARRIER();   // every wave executes the same number of barriers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
+
+    if constexpr (CL) {   // D[r][c] of a fragment: r = 4*(lane>>4) + reg -> channel, c = lane&15 -> pixel
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + qn * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
+                float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (OUT != kOutI32) {
+                    if (n < g.Cout) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            al[e] = g.alpha[n + e];
+                            if (g.bias) bi[e] = g.bias[n + e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
+                        if (m < g.M && n < g.Cout) store_pixel_channels<OUT>(g, m, n, acc[qm][qn][i][j], al, bi);
+                    }
+            }
+        return;
+    }
 
     // Epilogue.  D[r][c] of a fragment: r = 4*(lane>>4) + reg -> pixel, c = lane&15 -> output channel.
     const bool vec_ok = (g.HoWo & 3) == 0;
@@ -1110,25 +1189,29 @@ int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
     return check_launch("conv3x3_planar_kernel");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool CL = false>
 int launch_tile(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
     const int lds = 2 * (BM + BN) * kTileK;
-    auto kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false>;
-    if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
+    void (*kern)(ConvArgs) = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false, CL>;
+    if constexpr (!CL) {
+        if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
+    }
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
     return check_launch("conv_i8_kernel");
 }
 
-template <int OUT>
+template <int OUT, bool CL = false>
 int launch_pipe(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, 256));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, 256));
     constexpr int lds = 2 * 4 * 128 * kTileK;
-    auto kern = conv_i8_pipe_kernel<OUT, false>;
-    if (g.stream_out) kern = conv_i8_pipe_kernel<OUT, true>;
+    void (*kern)(ConvArgs) = conv_i8_pipe_kernel<OUT, false, CL>;
+    if constexpr (!CL) {
+        if (g.stream_out) kern = conv_i8_pipe_kernel<OUT, true>;
+    }
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 512, lds, st>>>(g);
     return check_launch("conv_i8_pipe_kernel");
@@ -1156,6 +1239,16 @@ int launch(const ConvArgs& g, hipStream_t st) {
     if (g.Cout > 128) return launch_tile<128, 128, 2, 2, OUT>(g, st);
     if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT>(g, st);
     return launch_tile<128, 64, 2, 2, OUT>(g, st);
+}
+
+// The same tile choice for the channels-last entry point.
+template <int OUT>
+int launch_cl(const ConvArgs& g, hipStream_t st) {
+    auto tiles = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.Cout, bn); };
+    if (g.Cout > 128 && tiles(256, 256) >= 160) return launch_pipe<OUT, true>(g, st);
+    if (g.Cout > 128) return launch_tile<128, 128, 2, 2, OUT, true>(g, st);
+    if (g.Cout <= 64 && tiles(256, 64) >= 200) return launch_tile<256, 64, 4, 2, OUT, true>(g, st);
+    return launch_tile<128, 64, 2, 2, OUT, true>(g, st);
 }
 
 // dst[c][r] = src[r][c], any shape, byte accesses through a padded LDS tile.
@@ -1361,5 +1454,81 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             return launch<kOutBF16>(a, st);
         default:
             return launch<kOutI32>(a, st);
+    }
+}
+
+// ---- channels-last entry points ---------------------------------------------------------------------
+extern "C" size_t miq_conv2d_i8_packed_weight_bytes(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
+    if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+    const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
+    return static_cast<size_t>(Cout * KH * Lp);
+}
+
+extern "C" int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int8_t* wp,
+                                         void* stream) {
+    MIQ_REQUIRE(Cin > 0 && Cout >= 0 && KH > 0 && KW > 0, MIQ_EINVAL, "miq_conv2d_i8_pack_weight: bad shape");
+    if (Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(w && wp, MIQ_EINVAL, "miq_conv2d_i8_pack_weight: null pointer");
+    MIQ_REQUIRE(miq::aligned(wp, 16), MIQ_EALIGN, "miq_conv2d_i8_pack_weight: wp must be 16-byte aligned");
+    const int64_t Cp = miq::round_up(Cin, kCinAlign), L = KW * Cp, Lp = miq::round_up(L, kChunk);
+    const int64_t bytes = Cout * KH * Lp;
+    MIQ_REQUIRE(bytes < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_pack_weight: packed weight beyond 2 GiB");
+    const uint32_t total = static_cast<uint32_t>(bytes / 4);
+    const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+    pack_conv_weight_kernel<<<wgrid, 256, 0, miq::as_stream(stream)>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)Cp, (int)L,
+                                                                       (int)Lp);
+    return miq::check_launch("pack_conv_weight_kernel");
+}
+
+extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                                  int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                                  const float* alpha, float beta, void* out, int out_dtype, int64_t out_pad, void* stream) {
+    ConvGeom G;
+    MIQ_REQUIRE(make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G, false) && out_pad >= 0, MIQ_EINVAL,
+                "miq_conv2d_i8_nhwc: bad geometry (B=%lld Cin=%lld H=%lld W=%lld Cout=%lld KH=%lld KW=%lld stride=%lld pad=%lld)",
+                (long long)B, (long long)Cin, (long long)H, (long long)W, (long long)Cout, (long long)KH,
+                (long long)KW, (long long)stride, (long long)pad);
+    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32 || out_dtype == MIQ_I8, MIQ_EINVAL,
+                "miq_conv2d_i8_nhwc: out_dtype must be MIQ_I8, MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", out_dtype);
+    MIQ_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, MIQ_EINVAL,
+                "miq_conv2d_i8_nhwc: channel counts must be multiples of 4 (Cin=%lld Cout=%lld)", (long long)Cin, (long long)Cout);
+    if (G.M == 0 || Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(x && wp && out, MIQ_EINVAL, "miq_conv2d_i8_nhwc: null pointer");
+    MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "miq_conv2d_i8_nhwc: alpha is required for a dequantised output");
+    const int64_t Hop = G.Ho + 2 * out_pad, Wop = G.Wo + 2 * out_pad;
+    MIQ_REQUIRE(G.xp_bytes < (1ll << 31) && G.wp_bytes < (1ll << 31) && G.M < (1ll << 31) && B < 65536 && G.Hp < 65536 &&
+                    B * Hop * Wop * Cout < (1ll << 31),
+                MIQ_ERANGE, "miq_conv2d_i8_nhwc: activations, packed weights and output are indexed with 31 bits");
+    MIQ_REQUIRE(G.Kp / kChunk <= 4096, MIQ_ERANGE, "miq_conv2d_i8_nhwc: KH*KW*Cin too large (%lld > 65536)", (long long)G.Kp);
+    const size_t esz = out_dtype == MIQ_I8 ? 1 : out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(miq::aligned(x, 16) && miq::aligned(wp, 16) && miq::aligned(out, 4 * esz) && miq::aligned(alpha, 4) &&
+                    miq::aligned(bias, 4),
+                MIQ_EALIGN, "miq_conv2d_i8_nhwc: x and wp must be 16-byte aligned, out aligned to four of its elements");
+
+    ConvArgs a{};
+    a.xp = x; a.wp = wp; a.bias = bias; a.alpha = alpha; a.out = out; a.beta = beta;
+    a.M = static_cast<int>(G.M);
+    a.Cout = static_cast<int>(Cout);
+    a.Kp = static_cast<int>(G.Kp);
+    a.HoWo = static_cast<int>(G.Ho * G.Wo);
+    a.Wo = static_cast<int>(G.Wo);
+    a.img_stride = static_cast<int>(G.Hp * G.Wp * G.Cp);
+    a.row_stride = static_cast<int>(G.Wp * G.Cp);
+    a.sx = static_cast<int>(stride * G.Cp);
+    a.sy = static_cast<int>(stride * G.Wp * G.Cp);
+    a.cps = static_cast<int>(G.Lp / kChunk);
+    a.cps_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(a.cps)) + 1u;
+    a.xp_bytes = static_cast<uint32_t>(G.xp_bytes);
+    a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
+    a.o_pix = static_cast<int>(Cout);
+    a.o_row = static_cast<int>(Wop * Cout);
+    a.o_img = static_cast<int>(Hop * Wop * Cout);
+    a.o_off = static_cast<int>((out_pad * Wop + out_pad) * Cout);
+    hipStream_t st = miq::as_stream(stream);
+    switch (out_dtype) {
+        case MIQ_F32: return launch_cl<kOutF32>(a, st);
+        case MIQ_BF16: return launch_cl<kOutBF16>(a, st);
+        case MIQ_I32: return launch_cl<kOutI32>(a, st);
+        default: return launch_cl<kOutI8>(a, st);
     }
 }

@@ -82,7 +82,7 @@ __device__ __forceinline__ void tile_coords(int pid, int nwg, int tiles_m, int t
     tn = in_band / gsz;
 }
 
-enum : int { kOutF32 = 0, kOutBF16 = 2, kOutI32 = 3 };  // == MIQ_F32 / MIQ_BF16 / MIQ_I32
+enum : int { kOutF32 = 0, kOutBF16 = 2, kOutI32 = 3, kOutI8 = 4 };  // == MIQ_F32 / MIQ_BF16 / MIQ_I32 / MIQ_I8
 
 // fp32 -> bf16, round-half-even, NaN stays NaN: the hardware conversion (v_cvt_pk_bf16_f32, two values
 // per instruction) instead of a dozen integer operations per value.
@@ -99,6 +99,15 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
     p.x = pack2_bf16(a, b);
     p.y = pack2_bf16(c, d);
     return p;
+}
+
+// Requantisation of a dequantised value to int8, the per-tensor form of Qop.quantize with the scale folded into
+// alpha (quant/Weight_Only/Qop.py:154-157): clamp(rint(y), -128, 127), round-half-even; four of them as one dword.
+__device__ __forceinline__ uint32_t requant4_i8(float a, float b, float c, float d) {
+    auto q = [](float y) {
+        return static_cast<uint32_t>(static_cast<int>(__builtin_amdgcn_fmed3f(__builtin_rintf(y), -128.0f, 127.0f))) & 0xffu;
+    };
+    return q(a) | (q(b) << 8) | (q(c) << 16) | (q(d) << 24);
 }
 
 // Two MFMA result fragments X and Y, each packed as four bf16 (8 bytes) per lane, where the 16-lane row
