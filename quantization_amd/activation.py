@@ -18,6 +18,11 @@ and the layer forward `scale_w[n] * (x_hat . Wq^T + b[n])` of the weight-only Qu
 
 which is the GEMM's fused epilogue with a per-call bias and alpha.  Nothing here synchronises with
 the host: the two statistics, the parameters and the epilogue vectors stay on the device.
+
+A convolution is the same expression once its padding is made explicit: a padded position holds the
+real value 0, whose quantized form is the zero point, not 0, so the quantized image is framed with
+zero_point and convolved without padding; every window is then full and the correction term stays
+the per-channel constant zero_point * sum(Wq[n]).
 """
 import torch
 
@@ -70,3 +75,23 @@ def linear_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, out_dtype=torc
     xq = _native.quantize_rows_given_i8(x2, scale_zp[0:1], scale_zp[1:2])
     y = _native.gemm_i8(xq, wq, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
     return y.view(*lead, y.shape[-1])
+
+
+@torch.no_grad()
+def conv2d_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, stride=1, padding=0, out_dtype=torch.float32):
+    """Weight-only quantized Conv2d (dilation 1, groups 1) on a float activation x [B, Cin, H, W], through the
+    int8 convolution: x is quantized per tensor on the fly into a frame filled with its zero point, and the
+    zero-point correction, both scales and the bias ride the fused epilogue.  Nothing on the host."""
+    _native.require_device(x, "input")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    if w_rowsum is None:
+        w_rowsum = weight_rowsum(wq)
+    scale_zp, alpha, corr = _native.dynamic_epilogue_i8(_native.tensor_minmax(x), w_scale.reshape(-1), bias, w_rowsum)
+    xq = _native.quantize_rows_given_i8(x.view(B * C, H * W), scale_zp[0:1], scale_zp[1:2]).view(B, C, H, W)
+    if padding:
+        framed = torch.empty((B, C, H + 2 * padding, W + 2 * padding), dtype=torch.int8, device=x.device)
+        framed.copy_(scale_zp[1].to(torch.int8))          # the zero point is integral and within [-128, 127]
+        framed[:, :, padding:padding + H, padding:padding + W].copy_(xq)
+        xq = framed
+    return _native.conv2d_i8(xq, wq, stride, 0, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)

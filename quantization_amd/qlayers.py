@@ -236,11 +236,11 @@ class WeightOnlyQuantizer(_QuantizerBase):
         if not (wq.symmetric and wq.dtype == torch.int8):
             # zero_point is identically 0 for symmetric int8, the only form quantize() produces
             raise NotImplementedError("only symmetric int8 weights are implemented")
-        if self.input_quant and not self.cnn and x.dtype.is_floating_point:
+        if self.input_quant and x.dtype.is_floating_point:
             # The step the reference leaves commented out (Quantizer.py:69-70): quantize the activation per
-            # tensor and take the int8 product (see quantization_amd/activation.py).  Linear only: an
-            # asymmetric activation needs its zero point, not 0, as the convolution's padding value.
-            from .activation import linear_dynamic_w8a8, weight_rowsum
+            # tensor and take the int8 product (see quantization_amd/activation.py; a convolution's padding
+            # is filled with the activation's zero point there).
+            from .activation import conv2d_dynamic_w8a8, linear_dynamic_w8a8, weight_rowsum
             if self._params_stale:
                 raise RuntimeError(self._params_stale)
             home = x.device
@@ -248,7 +248,14 @@ class WeightOnlyQuantizer(_QuantizerBase):
             if getattr(self, "_rowsum_src", None) is not self.weight:
                 self._rowsum, self._rowsum_src = weight_rowsum(w), self.weight
             bias = None if self.bias is None else _to_gpu(self.bias.detach())
-            y = linear_dynamic_w8a8(_to_gpu(x).to(torch.float32), w, _to_gpu(wq.scales), bias, self._rowsum)
+            xg = _to_gpu(x).to(torch.float32)
+            if self.cnn:
+                if _single(self.dilation) != 1 or self.groups != 1 or isinstance(self.padding, str):
+                    raise NotImplementedError("the int8 convolution implements dilation 1, groups 1, numeric padding")
+                y = conv2d_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum, _single(self.stride),
+                                        _single(self.padding))
+            else:
+                y = linear_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum)
             return y.to(home)
         y = self._run(x, self.bias, wq.scales, 0.0)
         # the reference's dequantize(activation=True) leaves the parameters re-viewed [1,N,...] (Qop.py:175-177)

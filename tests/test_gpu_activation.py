@@ -99,6 +99,52 @@ def test_quantizer_input_quant_flag():
     assert 0.0 < rel < 0.03, rel
 
 
+@pytest.mark.parametrize("B,C,H,Co,k,stride,pad,bias", [(2, 16, 12, 32, 3, 1, 1, True), (3, 3, 17, 8, 7, 2, 3, True),
+                                                        (2, 64, 9, 64, 1, 2, 0, False), (1, 5, 8, 7, 3, 1, 2, True)])
+def test_conv2d_dynamic_w8a8(B, C, H, Co, k, stride, pad, bias):
+    """The convolution form: scale_w[n] * (conv(x_hat, Wq) + b[n]) with x_hat the dequantized activation and real
+    zeros in the padding (which is what a frame of zero points dequantizes to), evaluated in float64."""
+    from quantization_amd import _native as Nv
+    from quantization_amd.activation import conv2d_dynamic_w8a8, quantize_tensor_i8
+    g = torch.Generator(device="cuda").manual_seed(B + C + H)
+    w = torch.randn(Co, C, k, k, generator=g, device="cuda") * 0.05
+    b = torch.randn(Co, generator=g, device="cuda") if bias else None
+    x = torch.randn(B, C, H, H, generator=g, device="cuda") * 1.5 + 0.7       # off-centre: a zero point far from 0
+    wq, ws, _ = Nv.quantize_rows_sym_i8(w.view(Co, -1))
+    wq = wq.view(Co, C, k, k)
+    y = conv2d_dynamic_w8a8(x, wq, ws, b, stride=stride, padding=pad)
+    xq, sx, zx = quantize_tensor_i8(x)
+    assert int(zx) != 0
+    x_hat = ((xq.double() - zx.double()) * sx.double()).cpu()
+    ref = torch.nn.functional.conv2d(x_hat, wq.double().cpu(), stride=stride, padding=pad)
+    if bias:
+        ref = ref + b.double().cpu().view(1, -1, 1, 1)
+    ref = ref * ws.double().cpu().view(1, -1, 1, 1)
+    assert y.shape == ref.shape
+    assert float((y.double().cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_quantizer_input_quant_flag_conv():
+    """`input_quant = True` on a Conv2d layer: the dynamic int8 convolution, within the activation's quantization
+    noise of the float-activation forward, borders included."""
+    from quantization_amd.quant.Weight_Only.Quantizer import Quantizer
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(16, 32, 3, stride=1, padding=1)
+    qp = {'weights': {'dtype': torch.int8, 'symmetric': True, 'affine': 'channel', 'affine_dim': 0}}
+    q = Quantizer.from_float(conv, data_metry=qp)
+    x = torch.randn(4, 16, 20, 20) + 0.5
+    y_float = q(x)
+    q.input_quant = True
+    y_int8 = q(x)
+    assert y_int8.shape == y_float.shape and y_int8.device == x.device
+    rel = float((y_int8 - y_float).norm() / y_float.norm())
+    assert 0.0 < rel < 0.03, rel
+    border = torch.ones_like(y_float, dtype=torch.bool)
+    border[:, :, 1:-1, 1:-1] = False
+    rel_b = float((y_int8 - y_float)[border].norm() / y_float[border].norm())
+    assert rel_b < 0.03, rel_b
+
+
 def test_activation_entry_points_reject_bad_arguments():
     """Argument checks of the C entry points, through ctypes: every failure is reported before any launch."""
     import ctypes
