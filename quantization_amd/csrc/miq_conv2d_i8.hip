@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "miq_common.h"
 #include "miq_gemm_core.h"
 
@@ -325,6 +327,11 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const int8_t* __r
                                                                uint32_t total_dwords, int Cin, int KH, int KW, int Cp, int L,
                                                                int Lp) {
     pack_conv_weight_items(w, wp, total_dwords, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256u + threadIdx.x, 256u * gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void pack_conv_weight_planar_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wp,
+                                                                      uint32_t total_dwords, int Cin, int Cout) {
+    pack_conv_weight_planar_items(w, wp, total_dwords, Cin, Cout, blockIdx.x * 256u + threadIdx.x, 256u * gridDim.x);
 }
 
 template <bool DWORD>
@@ -968,7 +975,20 @@ struct PlanarArgs {
     uint32_t wo_magic;            // floor(2^32 / Wo) + 1
     uint32_t xp_bytes, wp_bytes;
     int wide16;                   // bf16 output: paired 16-byte stores (HoWo % 8 == 0, 16-byte aligned output)
+    int abl;                      // developer library only (timing; results are then wrong): bit 0 no output stores,
+                                  // bit 1 no patch fetch, bit 2 no MFMA loop
+    // channels-last form (CL kernels): xp is the caller's [image][padded row][padded column][cin] activation and
+    // out[b][y + border][x + border][channel] is addressed with these element strides
+    int cin;
+    int o_img, o_row, o_pix, o_off;
+    unsigned long long* stamps;   // developer library only: [workgroup][stage 0..7][8] shader-clock stamps, or null
 };
+
+#ifdef MIQ_NO_DEV_SWITCHES
+#define MIQ_PLANAR_ABL(g, bit) false
+#else
+#define MIQ_PLANAR_ABL(g, bit) (((g).abl >> (bit)) & 1)
+#endif
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 16] (the instruction takes an immediate).
 __device__ __forceinline__ void wait_vmcnt_upto16(int n) {
@@ -982,7 +1002,11 @@ __device__ __forceinline__ void wait_vmcnt_upto16(int n) {
     }
 }
 
-template <int OUT, bool STREAM>
+// CL = channels-last activations in and out.  The patch is then gathered from pixel-major memory (a lane's 16 bytes are
+// chunk `plane` of its pixel, cin bytes apart from its neighbour's) into the same chunk planes, the weight fragment is
+// the MFMA's first operand, and its rows are read in an order that leaves a lane with eight consecutive output channels
+// of one pixel: one 8-byte store per fragment row for an int8 output.
+template <int OUT, bool STREAM, bool CL = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) {   // 4 waves per SIMD: two workgroups per CU
     constexpr int FM = 7, FN = 2;   // per wave: 7 pixel fragments x 2 channel fragments; waves 4 (pixels) x 2 (channels)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1011,9 +1035,16 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
         // (loops kept rolled: once per stage, and unrolled their wave-uniform addresses crowd the scalar registers)
 #pragma unroll 1
         for (int q = wave; q < 44; q += 8) {
-            const int plane = q / 11, seg = q - plane * 11;
+            if (MIQ_PLANAR_ABL(g, 1)) break;
+            // channels-last: the four planes of a 64-pixel segment are read from the same cache lines, so they go out
+            // together (from four waves at once): issued plane by plane, a line has left the L1 before its next use
+            const int plane = CL ? (q & 3) : q / 11, seg = CL ? (q >> 2) : q - plane * 11;
             // behind the rows the tile needs, the run continues into later rows (or past the buffer: zeros)
-            const uint32_t off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
+            uint32_t off;
+            if constexpr (CL)
+                off = (first + seg * 64 + lane) * g.cin + (cg * 4 + plane) * kChunk;
+            else
+                off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
             dma16(rx, stage + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
         }
 #pragma unroll 1
@@ -1029,7 +1060,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
 
     // Epilogue.  D[i][j]: i = 4*(lane>>4) + reg -> pixel, j = lane&15 -> output channel.  Returns the number
     // of store instructions it issued (wave-uniform): the caller's counted vmcnt leaves exactly those in flight.
-    auto epilogue = [&](const Unit& u) -> int {
+    auto epilogue_nchw = [&](const Unit& u) -> int {
         int issued = 0;
         float al[FN], bi[FN];
 #pragma unroll
@@ -1088,7 +1119,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
                 const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
                 const v4i a = acc[i][j];
                 acc[i][j] = v4i{0, 0, 0, 0};
-                const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout;
+                const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout && !MIQ_PLANAR_ABL(g, 0);
                 if (__ballot(mine) == 0) continue;   // wave-uniform: no store instruction for this fragment
                 ++issued;
                 if (!mine) continue;
@@ -1119,8 +1150,94 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
         return issued;
     };
 
-    const int w_lane = ((lane >> 4) * 64 + wn * 32 + (lane & 15)) * kChunk;
+    // Channels-last epilogue.  D[i][j] with the operands swapped: row 4*(lane>>4) + reg -> output channel, column
+    // lane&15 -> pixel; with the weight rows read in the order below, fragments j = 0, 1 of a lane are channels
+    // n0 .. n0+3 and n0+4 .. n0+7.
+    auto epilogue_cl = [&](const Unit& u) -> int {
+        int issued = 0;
+        const int n0 = u.tn * 64 + wn * 32 + (lane >> 4) * 8;
+        float al[8], bi[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            al[c] = 1.f;
+            bi[c] = 0.f;
+        }
+        if constexpr (OUT != kOutI32) {
+            const v4f a0 = *reinterpret_cast<const v4f*>(g.alpha + n0), a1 = *reinterpret_cast<const v4f*>(g.alpha + n0 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                al[c] = a0[c];
+                al[c + 4] = a1[c];
+            }
+            if (g.bias) {
+                const v4f b0 = *reinterpret_cast<const v4f*>(g.bias + n0), b1 = *reinterpret_cast<const v4f*>(g.bias + n0 + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bi[c] = b0[c];
+                    bi[c + 4] = b1[c];
+                }
+            }
+        }
+        uint32_t pfirst = u.p0 + wm * FM * 16 + (lane & 15);
+        asm volatile("" : "+v"(pfirst));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const uint32_t p = pfirst + i * 16;
+            const v4i a0 = acc[i][0], a1 = acc[i][1];
+            acc[i][0] = v4i{0, 0, 0, 0};
+            acc[i][1] = v4i{0, 0, 0, 0};
+            const bool mine = p < static_cast<uint32_t>(g.HoWo) && !MIQ_PLANAR_ABL(g, 0);
+            if (__ballot(mine) == 0) continue;   // wave-uniform
+            issued += (OUT == kOutI32 || OUT == kOutF32) ? 2 : 1;
+            if (!mine) continue;
+            const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
+            const size_t idx = static_cast<size_t>(u.b) * g.o_img + static_cast<size_t>(y) * g.o_row + x * g.o_pix + g.o_off + n0;
+            if constexpr (OUT == kOutI32) {
+                v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
+                o[0] = a0;
+                o[1] = a1;
+            } else {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = dequant1(a0[c], bi[c], al[c], g.beta);
+                    v[c + 4] = dequant1(a1[c], bi[c + 4], al[c + 4], g.beta);
+                }
+                if constexpr (OUT == kOutF32) {
+                    v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
+                    o[0] = v4f{v[0], v[1], v[2], v[3]};
+                    o[1] = v4f{v[4], v[5], v[6], v[7]};
+                } else if constexpr (OUT == kOutBF16) {
+                    const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(g.out) + idx) = uint4{lo.x, lo.y, hi.x, hi.y};
+                } else {
+                    *reinterpret_cast<uint2*>(static_cast<int8_t*>(g.out) + idx) =
+                        uint2{requant4_i8(v[0], v[1], v[2], v[3]), requant4_i8(v[4], v[5], v[6], v[7])};
+                }
+            }
+        }
+        return issued;
+    };
+    auto epilogue = [&](const Unit& u) -> int {
+        if constexpr (CL)
+            return epilogue_cl(u);
+        else
+            return epilogue_nchw(u);
+    };
 
+    // weight row of this lane inside a tap's [chunk][channel][16 B] block; fragment j is kWFrag bytes further
+    const int w_lane = CL ? ((lane >> 4) * 64 + wn * 32 + ((lane & 15) >> 2) * 8 + (lane & 3)) * kChunk
+                          : ((lane >> 4) * 64 + wn * 32 + (lane & 15)) * kChunk;
+    constexpr int kWFrag = CL ? 4 * kChunk : 16 * kChunk;
+
+#ifndef MIQ_NO_DEV_SWITCHES
+    int stamp_it = 0;   // developer library: shader-clock stamps of the first eight stages of every workgroup
+#define MIQ_PLANAR_STAMP(k)                                                                         \
+    if (g.stamps && threadIdx.x == 0 && stamp_it < 8)                                               \
+        g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define MIQ_PLANAR_STAMP(k)
+#endif
     bool pending = false;   // the previous unit's accumulators wait to be stored
     Unit prev{};
     for (int unit = blockIdx.x; unit < g.units; unit += gridDim.x) {
@@ -1137,29 +1254,35 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
             aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + ((y - u.y0) * g.pitch + x) * kChunk;
         }
         for (int cg = 0; cg < g.ncg; ++cg) {
+            MIQ_PLANAR_STAMP(0)
             issue(u, cg, smem);
+            MIQ_PLANAR_STAMP(1)
             int stores = 0;
             if (pending) {   // the previous unit's stores go out under this stage's fetch
                 stores = epilogue(prev);
                 pending = false;
             }
+            MIQ_PLANAR_STAMP(2)
             // The stage has landed once all but the `stores` youngest operations are done (vector memory
             // operations retire in issue order): the stores themselves are not waited for, so they drain
             // under the MFMAs below instead of holding the workgroup until memory has taken them.
             wait_vmcnt_upto16(stores);
+            MIQ_PLANAR_STAMP(3)
             __syncthreads();
+            MIQ_PLANAR_STAMP(4)
             // One filter row per iteration, kept as a loop: unrolled over all nine taps the compiler
             // prefetches fragments across taps and spills at the 128 registers two workgroups per CU allow;
             // four waves per SIMD hide the fragment reads instead.
 #pragma unroll 1
             for (int kh = 0; kh < 3; ++kh) {
+                if (MIQ_PLANAR_ABL(g, 2)) break;
                 const char* arow = smem + kh * g.pitch * kChunk;
                 const char* wrow = smem + kPatchBytes + kh * (3 * 4096) + w_lane;
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     v4i wf[FN];
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wrow + kw * 4096 + j * 256);
+                    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wrow + kw * 4096 + j * kWFrag);
                     v4i af[FM];
 #pragma unroll
                     for (int i = 0; i < FM; ++i) af[i] = lds_read16(arow + aoff[i] + kw * kChunk);
@@ -1167,10 +1290,16 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
                 }
             }
+            MIQ_PLANAR_STAMP(5)
             __syncthreads();   // the stage is read: the next one may overwrite it
+            MIQ_PLANAR_STAMP(6)
+#ifndef MIQ_NO_DEV_SWITCHES
+            ++stamp_it;
+#endif
         }
         prev = u;
         pending = true;
@@ -1178,15 +1307,366 @@ __global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) { 
     if (pending) (void)epilogue(prev);
 }
 
-template <int OUT>
+
+// The same convolution with ONE workgroup per CU (256 registers a wave) and the phases of a stage overlapped in
+// software instead of across two workgroups, which at two waves per SIMD each spent most of a stage outside its MFMA
+// loop (shader-clock stamps: fetch issue + epilogue + barrier skew 12,500 cycles against 5,800 in the loop):
+//   * LDS holds two stages: the fetch of stage s + 1 is issued at the top of stage s and lands under its MFMAs;
+//   * the fragments of filter tap t + 1 are read from LDS while the MFMAs of tap t run;
+//   * a finished unit's accumulators move to a second register set and leave, one fragment row per filter tap, among
+//     the MFMAs of the next unit's first stage: their conversion is VALU work between matrix instructions and their
+//     stores trickle out instead of queueing in one burst in front of the next fetch.
+// One barrier per stage.  A workgroup keeps one channel tile (the grid is a multiple of tiles_n), so its per-channel
+// epilogue parameters are loaded once, and with a single input-channel group its weights are too.
+template <int OUT, bool STREAM, bool CL>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
+    constexpr int FM = 7, FN = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, then [2] weight stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+    const bool w_once = g.ncg == 1;   // every stage of this workgroup multiplies by the same weights
+
+    struct Unit {
+        uint32_t b, p0, y0, tn;
+    };
+    auto decode = [&](int unit) {
+        Unit u;
+        u.tn = static_cast<uint32_t>(unit % g.tiles_n);
+        const uint32_t t = static_cast<uint32_t>(unit / g.tiles_n);
+        u.b = t / g.tiles_img;
+        u.p0 = (t - u.b * g.tiles_img) * kTM;
+        u.y0 = u.p0 / g.Wo;
+        return u;
+    };
+    // One stage's fetch is 44 wave-instructions of patch and 36 of weights, dealt over the eight waves: piece k of a wave
+    // is patch instruction wave + 8k (k < 6) and weight instruction wave + 8k (k < 5).  Returns whether it issued any.
+    auto issue_piece = [&](const Unit& u, int cg, int buf, bool weights, int k) -> bool {
+        bool any = false;
+        const int q = wave + 8 * k;
+        if (q < 44) {
+            const uint32_t first = (u.b * g.Hp + u.y0) * g.pitch;
+            // channels-last: the four planes of a 64-pixel segment are read from the same cache lines, so they go out
+            // together (from four waves at once): issued plane by plane, a line has left the L1 before its next use
+            const int plane = CL ? (q & 3) : q / 11, seg = CL ? (q >> 2) : q - plane * 11;
+            uint32_t off;
+            if constexpr (CL)
+                off = (first + seg * 64 + lane) * g.cin + (cg * 4 + plane) * kChunk;
+            else
+                off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
+            dma16(rx, smem + buf * kPatchBytes + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
+            any = true;
+        }
+        if (weights && q < 36) {
+            dma16(rw, smem + 2 * kPatchBytes + (w_once ? 0 : buf) * kWStageBytes + q * 1024,
+                  ((u.tn * g.ncg + cg) * 36 + q) * 1024 + lane * kChunk);
+            any = true;
+        }
+        return any;
+    };
+
+    // per-channel epilogue parameters of this workgroup's channel tile, once
+    const int tn_mine = static_cast<int>(blockIdx.x) % g.tiles_n;
+    constexpr int kParams = CL ? 8 : FN;
+    float al[kParams], bi[kParams];
+#pragma unroll
+    for (int c = 0; c < kParams; ++c) {
+        al[c] = 1.f;
+        bi[c] = 0.f;
+    }
+    if constexpr (OUT != kOutI32) {
+#pragma unroll
+        for (int c = 0; c < kParams; ++c) {
+            const int n = CL ? tn_mine * 64 + wn * 32 + (lane >> 4) * 8 + c : tn_mine * 64 + wn * 32 + c * 16 + (lane & 15);
+            if (n < g.Cout) {
+                al[c] = g.alpha[n];
+                if (g.bias) bi[c] = g.bias[n];
+            }
+        }
+    }
+
+    v4i acc[FM][FN], done[FM][FN];   // the unit being accumulated; the finished one on its way out
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = done[i][j] = v4i{0, 0, 0, 0};
+
+    // One fragment row (or, bf16 NCHW with 16-byte stores, one pair of rows) of the finished unit, as buffer stores
+    // into the unit's image: a lane with nothing to store (pixels past the image, channels past Cout) gets an offset
+    // past the buffer, which the hardware drops.  No branch, so the conversion shares a basic block with the tap's MFMAs
+    // and is scheduled among them, and the number of store instructions is a constant (what the counted wait needs).
+    constexpr int kEsz = OUT == kOutI8 ? 1 : OUT == kOutBF16 ? 2 : 4;
+    constexpr int kNt = (STREAM && !CL) ? 2 : 0;   // cache policy of the output stores: 2 = nontemporal
+    auto put16 = [&](__amdgpu_buffer_rsrc_t r, uint32_t off, v4i v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, kNt); };
+    auto put8 = [&](__amdgpu_buffer_rsrc_t r, uint32_t off, uint2 v) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{v.x, v.y}, r, off, 0, kNt);
+    };
+    auto store_row_cl = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
+        constexpr int i = decltype(I)::value;
+        const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane & 15);
+        const int n0 = u.tn * 64 + wn * 32 + (lane >> 4) * 8;
+        v4i a0 = done[i][0], a1 = done[i][1];
+        // (opaque: the conversion below then stays at this point of the instruction stream, among the MFMAs of the tap
+        // it was written beside, instead of being computed for the whole unit ahead of the first tap)
+        asm volatile("" : "+v"(a0), "+v"(a1));
+        const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
+        const uint32_t off = p < static_cast<uint32_t>(g.HoWo) ? (y * g.o_row + x * g.o_pix + g.o_off + n0) * kEsz : kOob;
+        if constexpr (OUT == kOutI32) {
+            put16(r, off, a0);
+            put16(r, off + 16, a1);
+            return 2;
+        } else {
+            float v[8];
+            const v2f beta2{g.beta, g.beta};
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const v2f lo = dequant2(a0[c], a0[c + 1], v2f{bi[c], bi[c + 1]}, v2f{al[c], al[c + 1]}, beta2);
+                const v2f hi = dequant2(a1[c], a1[c + 1], v2f{bi[c + 4], bi[c + 5]}, v2f{al[c + 4], al[c + 5]}, beta2);
+                v[c] = lo[0];
+                v[c + 1] = lo[1];
+                v[c + 4] = hi[0];
+                v[c + 5] = hi[1];
+            }
+            if constexpr (OUT == kOutF32) {
+                put16(r, off, v4i{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])});
+                put16(r, off + 16, v4i{__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])});
+                return 2;
+            } else if constexpr (OUT == kOutBF16) {
+                const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+                put16(r, off, v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y});
+                return 1;
+            } else {
+                put8(r, off, uint2{requant4_i8(v[0], v[1], v[2], v[3]), requant4_i8(v[4], v[5], v[6], v[7])});
+                return 1;
+            }
+        }
+    };
+    auto store_row_nchw = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
+        constexpr int i = decltype(I)::value;
+        const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4;   // HoWo % 4 == 0: four pixels in or out together
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+            v4i a = done[i][j];
+            asm volatile("" : "+v"(a));   // (opaque, as above)
+            const uint32_t off = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout ? (n * g.HoWo + p) * kEsz : kOob;
+            if constexpr (OUT == kOutI32) {
+                put16(r, off, a);
+            } else {
+                const v2f b2{bi[j], bi[j]}, a2{al[j], al[j]}, beta2{g.beta, g.beta};
+                const v2f lo = dequant2(a[0], a[1], b2, a2, beta2), hi = dequant2(a[2], a[3], b2, a2, beta2);
+                const float y0 = lo[0], y1 = lo[1], y2 = hi[0], y3 = hi[1];
+                if constexpr (OUT == kOutF32)
+                    put16(r, off, v4i{__float_as_int(y0), __float_as_int(y1), __float_as_int(y2), __float_as_int(y3)});
+                else
+                    put8(r, off, pack4_bf16(y0, y1, y2, y3));
+            }
+        }
+        return FN;
+    };
+    // bf16 NCHW, 16-byte stores: fragment rows i - 1 and i trade 16-lane rows, a lane stores eight pixels of its channel
+    auto store_pair_nchw_bf16 = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
+        constexpr int i = decltype(I)::value;   // the second row of the pair
+        const uint32_t p = u.p0 + wm * FM * 16 + (i - 1) * 16 + paired_offset(lane);   // HoWo % 8 == 0
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+            uint2 h[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v4i a = done[i - 1 + e][j];
+                asm volatile("" : "+v"(a));   // (opaque, as above)
+                const v2f b2{bi[j], bi[j]}, a2{al[j], al[j]}, beta2{g.beta, g.beta};
+                const v2f lo = dequant2(a[0], a[1], b2, a2, beta2), hi = dequant2(a[2], a[3], b2, a2, beta2);
+                h[e] = pack4_bf16(lo[0], lo[1], hi[0], hi[1]);
+            }
+            const v4i v = pair_rows_bf16(h[0], h[1]);
+            put16(r, p < static_cast<uint32_t>(g.HoWo) && n < g.Cout ? (n * g.HoWo + p) * kEsz : kOob, v);
+        }
+        return FN;
+    };
+    // what leaves beside filter tap T of the next unit's first stage
+    auto store_step = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto T) -> int {
+        constexpr int t = decltype(T)::value;
+        if constexpr (t >= FM) {
+            return 0;
+        } else if constexpr (CL) {
+            return store_row_cl(r, u, T);
+        } else if constexpr (OUT == kOutBF16) {
+            if (g.wide16) {
+                if constexpr (t % 2 == 1)
+                    return store_pair_nchw_bf16(r, u, T);
+                else if constexpr (t == FM - 1)
+                    return store_row_nchw(r, u, T);
+                else
+                    return 0;
+            }
+            return store_row_nchw(r, u, T);
+        } else {
+            return store_row_nchw(r, u, T);
+        }
+    };
+    // the finished unit's image as a buffer (offsets inside one image fit 31 bits: checked by the host)
+    const uint32_t img_bytes = CL ? static_cast<uint32_t>(g.o_img) * kEsz : static_cast<uint32_t>(g.Cout) * g.HoWo * kEsz;
+    auto image_of = [&](const Unit& u) {
+        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, img_bytes);
+    };
+
+    const int w_lane = CL ? ((lane >> 4) * 64 + wn * 32 + ((lane & 15) >> 2) * 8 + (lane & 3)) * kChunk
+                          : ((lane >> 4) * 64 + wn * 32 + (lane & 15)) * kChunk;
+    constexpr int kWFrag = CL ? 4 * kChunk : 16 * kChunk;
+
+    // A workgroup's eight waves sit two to a SIMD (wave w with wave w + 4).  The second one goes first whenever both want
+    // to issue: it runs a tap's MFMAs while the first waits, then converts its row while the first one's MFMAs run.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#ifndef MIQ_NO_DEV_SWITCHES
+    int stamp_it = 0;
+#endif
+    int unit = blockIdx.x;
+    Unit cur = decode(unit);
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) (void)issue_piece(cur, 0, 0, true, k);
+    int buf = 0;
+    int stores = 0;         // store instructions this wave issued after its last piece of the next stage's fetch
+    bool pending = false;   // `done` holds a unit that has not left yet
+    Unit prev{};
+    __amdgpu_buffer_rsrc_t rout = image_of(cur);
+    for (; unit < g.units; unit += gridDim.x) {
+        cur = decode(unit);
+        int aoff[FM];   // patch address of each fragment row this lane supplies: plane lane>>4, pixel (y - y0) * pitch + x
+        {
+            uint32_t qfirst = cur.p0 + wm * FM * 16 + (lane & 15);
+            asm volatile("" : "+v"(qfirst));
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                uint32_t p = qfirst + i * 16;
+                if (p >= static_cast<uint32_t>(g.HoWo)) p = g.HoWo - 1;   // rows past the image: computed, never stored
+                const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
+                aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + ((y - cur.y0) * g.pitch + x) * kChunk;
+            }
+        }
+        for (int cg = 0; cg < g.ncg; ++cg) {
+            // This wave's pieces of the stage have landed once all but the stores it issued after the last of them are
+            // done (vector memory operations retire in issue order); the barrier tells the same of the other waves'
+            // pieces, and that every wave has left the stage before, whose buffers the next fetch overwrites.
+            MIQ_PLANAR_STAMP(0)
+            wait_vmcnt_upto16(stores);
+            stores = 0;
+            MIQ_PLANAR_STAMP(1)
+            __syncthreads();
+            MIQ_PLANAR_STAMP(2)
+            // the next stage, fetched piece by piece among this stage's taps
+            int ncg = cg + 1, nunit = unit;
+            if (ncg == g.ncg) {
+                ncg = 0;
+                nunit = unit + gridDim.x;
+            }
+            const bool fetch = nunit < g.units;
+            const Unit nxt = decode(fetch ? nunit : unit);
+            MIQ_PLANAR_STAMP(3)
+            const bool flush = pending && cg == 0;
+            const char* patch = smem + buf * kPatchBytes;
+            const char* wst = smem + 2 * kPatchBytes + (w_once ? 0 : buf) * kWStageBytes + w_lane;
+            {
+                v4i af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
+                auto read_tap = [&](auto S, int kh, int kw) {
+                    constexpr int s = decltype(S)::value;
+                    const char* arow = patch + (kh * g.pitch + kw) * kChunk;
+                    const char* wrow = wst + (kh * 3 + kw) * 4096;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[s][j] = lds_read16(wrow + j * kWFrag);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[s][i] = lds_read16(arow + aoff[i]);
+                };
+                auto tap = [&](auto T) {
+                    constexpr int t = decltype(T)::value, s = t & 1;
+                    if constexpr (t < 6) {
+                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_once, t)) stores = 0;
+                    }
+                    if constexpr (t + 1 < 9) read_tap(std::integral_constant<int, (t + 1) & 1>{}, (t + 1) / 3, (t + 1) % 3);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[s][j], af[s][i], acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[s][i], wf[s][j], acc[i][j], 0, 0, 0);
+                    // The finished unit's row t is converted and stored behind this tap's MFMAs, as a block of its own
+                    // behind a branch (scheduled together with the MFMAs, or with the nine taps as one block, the compiler
+                    // keeps so much in flight that it spills; left alone, it converts the whole unit ahead of the first tap).  The two waves of a SIMD run half a tap
+                    // apart (priorities below), so one's conversion is covered by the other's MFMAs.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (flush) stores += store_step(rout, prev, T);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                read_tap(std::integral_constant<int, 0>{}, 0, 0);
+                tap(std::integral_constant<int, 0>{});
+                tap(std::integral_constant<int, 1>{});
+                tap(std::integral_constant<int, 2>{});
+                tap(std::integral_constant<int, 3>{});
+                tap(std::integral_constant<int, 4>{});
+                tap(std::integral_constant<int, 5>{});
+                tap(std::integral_constant<int, 6>{});
+                tap(std::integral_constant<int, 7>{});
+                tap(std::integral_constant<int, 8>{});
+            }
+            MIQ_PLANAR_STAMP(4)
+#ifndef MIQ_NO_DEV_SWITCHES
+            MIQ_PLANAR_STAMP(5)
+            MIQ_PLANAR_STAMP(6)
+            ++stamp_it;
+#endif
+            if (flush) pending = false;
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                done[i][j] = acc[i][j];
+                acc[i][j] = v4i{0, 0, 0, 0};
+            }
+        prev = cur;
+        rout = image_of(prev);
+        pending = true;
+    }
+    if (pending) {
+        (void)store_step(rout, prev, std::integral_constant<int, 0>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 1>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 2>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 3>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 4>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 5>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 6>{});
+    }
+}
+
+template <int OUT, bool CL = false>
 int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
-    auto kern = conv3x3_planar_kernel<OUT, false>;
-    if (stream_out) kern = conv3x3_planar_kernel<OUT, true>;
-    constexpr int kLds = kPlanarStage;
+    const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 2 = the two-workgroups-per-CU kernel
+    if (sw && sw[0] == '2') {
+        void (*kern)(PlanarArgs) = conv3x3_planar_kernel<OUT, false, CL>;
+        if constexpr (!CL) {
+            if (stream_out) kern = conv3x3_planar_kernel<OUT, true>;
+        }
+        constexpr int kLds = kPlanarStage;
+        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+        const int grid = g.units < 512 ? g.units : 512;   // two persistent workgroups per CU
+        kern<<<grid, 512, kLds, st>>>(g);
+        return check_launch("conv3x3_planar_kernel");
+    }
+    void (*kern)(PlanarArgs) = conv3x3_patch_kernel<OUT, false, CL>;
+    if constexpr (!CL) {
+        if (stream_out) kern = conv3x3_patch_kernel<OUT, true, false>;
+    }
+    constexpr int kLds = 2 * kPlanarStage;   // all of a CU's LDS
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
-    const int grid = g.units < 512 ? g.units : 512;   // two persistent workgroups per CU
+    // one persistent workgroup per CU, each keeping one channel tile
+    int grid = g.units < 256 ? g.units : 256 - 256 % g.tiles_n;
+    if (grid < g.tiles_n) grid = g.units < g.tiles_n ? g.units : g.tiles_n;
     kern<<<grid, 512, kLds, st>>>(g);
-    return check_launch("conv3x3_planar_kernel");
+    return check_launch("conv3x3_patch_kernel");
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool CL = false>
@@ -1406,6 +1886,9 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
         pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)G.wp_bytes;
         pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
+        if (const char* abl = dev_switch("MIQ_PLANAR_ABL")) pa.abl = atoi(abl);   // developer library: timing ablations
+        if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
+            pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
         const int64_t units = B * pa.tiles_img * pa.tiles_n;
         MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
         pa.units = (int)units;
@@ -1458,10 +1941,31 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
 }
 
 // ---- channels-last entry points ---------------------------------------------------------------------
+// The packed weight of the channels-last entry point: the im2col-order form wp[Cout][KH][Lp] and, for 3 x 3 filters over
+// whole 64-channel groups, behind it (at the next multiple of 256 bytes) the form conv3x3_planar_kernel stages from.
+struct PackedWeight {
+    int64_t rows_bytes;     // the im2col-order form
+    int64_t planar_at;      // offset of the patch kernel's form; 0 = none
+    int64_t planar_bytes;
+    int64_t total;
+};
+
+PackedWeight packed_weight_layout(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
+    PackedWeight pw{};
+    const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
+    pw.rows_bytes = Cout * KH * Lp;
+    pw.total = pw.rows_bytes;
+    if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0) {
+        pw.planar_at = miq::round_up(pw.rows_bytes, 256);
+        pw.planar_bytes = (Cout / 64) * (Cin / 64) * kWStageBytes;
+        pw.total = pw.planar_at + pw.planar_bytes;
+    }
+    return pw;
+}
+
 extern "C" size_t miq_conv2d_i8_packed_weight_bytes(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
-    const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
-    return static_cast<size_t>(Cout * KH * Lp);
+    return static_cast<size_t>(packed_weight_layout(Cin, Cout, KH, KW).total);
 }
 
 extern "C" int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int8_t* wp,
@@ -1471,13 +1975,20 @@ extern "C" int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t C
     MIQ_REQUIRE(w && wp, MIQ_EINVAL, "miq_conv2d_i8_pack_weight: null pointer");
     MIQ_REQUIRE(miq::aligned(wp, 16), MIQ_EALIGN, "miq_conv2d_i8_pack_weight: wp must be 16-byte aligned");
     const int64_t Cp = miq::round_up(Cin, kCinAlign), L = KW * Cp, Lp = miq::round_up(L, kChunk);
-    const int64_t bytes = Cout * KH * Lp;
-    MIQ_REQUIRE(bytes < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_pack_weight: packed weight beyond 2 GiB");
-    const uint32_t total = static_cast<uint32_t>(bytes / 4);
+    const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
+    MIQ_REQUIRE(pw.total < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_pack_weight: packed weight beyond 2 GiB");
+    const uint32_t total = static_cast<uint32_t>(pw.rows_bytes / 4);
     const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
     pack_conv_weight_kernel<<<wgrid, 256, 0, miq::as_stream(stream)>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)Cp, (int)L,
                                                                        (int)Lp);
-    return miq::check_launch("pack_conv_weight_kernel");
+    if (int rc = miq::check_launch("pack_conv_weight_kernel")) return rc;
+    if (pw.planar_at) {
+        const uint32_t ptotal = static_cast<uint32_t>(pw.planar_bytes / 4);
+        const int pgrid = static_cast<int>(ptotal / 256 + 1 < 4096 ? ptotal / 256 + 1 : 4096);
+        pack_conv_weight_planar_kernel<<<pgrid, 256, 0, miq::as_stream(stream)>>>(w, wp + pw.planar_at, ptotal, (int)Cin, (int)Cout);
+        return miq::check_launch("pack_conv_weight_planar_kernel");
+    }
+    return MIQ_OK;
 }
 
 extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
@@ -1505,6 +2016,43 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
                     miq::aligned(bias, 4),
                 MIQ_EALIGN, "miq_conv2d_i8_nhwc: x and wp must be 16-byte aligned, out aligned to four of its elements");
 
+    hipStream_t st = miq::as_stream(stream);
+    // 3 x 3 / stride 1 over whole 64-channel groups: the kernel that keeps a tile's pixel patch in LDS, where its
+    // tiles are mostly pixels and the patch fits (the conditions of the NCHW entry point, with the caller's row
+    // pitch Wp in place of the workspace's).
+    const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
+    if (pw.planar_at && stride == 1 && G.M >= 4 * kTM && miq::aligned(out, 16) && miq::aligned(alpha, 16) &&
+        miq::aligned(bias, 16) && !(dev_switch("MIQ_CONV_PLANAR") && dev_switch("MIQ_CONV_PLANAR")[0] == '0')) {
+        const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
+        int64_t rows = 0;
+        for (int64_t p0 = 0; p0 < HoWo; p0 += kTM)
+            rows = std::max(rows, (std::min<int64_t>(p0 + kTM, HoWo) - 1) / G.Wo - p0 / G.Wo + 3);
+        if (rows * G.Wp + 2 <= kPlaneSlots && 5 * HoWo >= 4 * tiles_img * kTM && HoWo < 65536) {
+            PlanarArgs pa{};
+            pa.xp = x; pa.wp = wp + pw.planar_at; pa.bias = bias; pa.alpha = alpha; pa.out = out; pa.beta = beta;
+            pa.Cout = (int)Cout; pa.ncg = (int)(Cin / 64); pa.tiles_n = (int)(Cout / 64);
+            pa.tiles_img = (int)tiles_img;
+            pa.pitch = (int)G.Wp; pa.Hp = (int)G.Hp; pa.Wo = (int)G.Wo; pa.HoWo = (int)HoWo;
+            pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
+            pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)pw.planar_bytes;
+            pa.cin = (int)Cin;
+            pa.o_pix = (int)Cout; pa.o_row = (int)(Wop * Cout); pa.o_img = (int)(Hop * Wop * Cout);
+            pa.o_off = (int)((out_pad * Wop + out_pad) * Cout);
+            if (const char* abl = dev_switch("MIQ_PLANAR_ABL")) pa.abl = atoi(abl);
+            if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
+                pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
+            const int64_t units = B * pa.tiles_img * pa.tiles_n;
+            MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_nhwc: too many tiles");
+            pa.units = (int)units;
+            switch (out_dtype) {
+                case MIQ_F32: return launch_planar<kOutF32, true>(pa, false, st);
+                case MIQ_BF16: return launch_planar<kOutBF16, true>(pa, false, st);
+                case MIQ_I32: return launch_planar<kOutI32, true>(pa, false, st);
+                default: return launch_planar<kOutI8, true>(pa, false, st);
+            }
+        }
+    }
+
     ConvArgs a{};
     a.xp = x; a.wp = wp; a.bias = bias; a.alpha = alpha; a.out = out; a.beta = beta;
     a.M = static_cast<int>(G.M);
@@ -1524,7 +2072,6 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
     a.o_row = static_cast<int>(Wop * Cout);
     a.o_img = static_cast<int>(Hop * Wop * Cout);
     a.o_off = static_cast<int>((out_pad * Wop + out_pad) * Cout);
-    hipStream_t st = miq::as_stream(stream);
     switch (out_dtype) {
         case MIQ_F32: return launch_cl<kOutF32>(a, st);
         case MIQ_BF16: return launch_cl<kOutBF16>(a, st);

@@ -35,7 +35,9 @@ SHAPES = [  # B, Cin, H, W, Cout, k, stride, pad
     (2, 4, 9, 11, 8, 3, 1, 1), (3, 16, 13, 13, 24, 3, 2, 1), (2, 64, 14, 14, 64, 3, 1, 1), (1, 8, 7, 7, 4, 1, 1, 0),
     (2, 32, 12, 10, 36, 1, 2, 0), (4, 128, 14, 14, 256, 3, 1, 1), (2, 12, 20, 20, 16, 5, 2, 2), (2, 64, 8, 8, 200, 3, 1, 0),
     (70, 256, 14, 14, 256, 3, 1, 1),   # enough 256 x 256 tiles for the pipelined kernel (54 x ... pixels)
-    (256, 64, 28, 28, 64, 3, 1, 1),    # 256 x 64 tiles
+    (256, 64, 28, 28, 64, 3, 1, 1),    # the LDS-resident-patch kernel, two tiles per image
+    (3, 64, 56, 56, 64, 3, 1, 1), (4, 128, 28, 28, 128, 3, 1, 1),      # the same: one / two channel groups and channel tiles
+    (5, 64, 30, 26, 192, 3, 1, 1), (4, 64, 40, 40, 64, 3, 1, 0),        # ... a ragged last tile, no padding
 ]
 
 
