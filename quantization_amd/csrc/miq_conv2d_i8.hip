@@ -32,7 +32,7 @@ struct ConvGeom {
     int64_t B, Cin, H, W, Cout, KH, KW, stride, pad;
     int64_t Ho, Wo, Hp, Wp, Cp, L, Lp, Kp, M;
     int64_t xp_bytes, wp_bytes;
-    // 3 x 3 / stride 1 layers (conv3x3_planar_kernel): chunk-plane layout of the padded copy
+    // 3 x 3 / stride 1 layers (conv3x3_patch_kernel): chunk-plane layout of the padded copy
     bool planar;
     int64_t pitch;   // pixels per padded row (Wp rounded up to 4)
     int64_t ptot;    // flat padded pixels B * Hp * pitch
@@ -42,7 +42,7 @@ struct ConvGeom {
     int64_t sub, Hs, Ws;
 };
 
-// conv3x3_planar_kernel's tile: kTM output pixels of one image x 64 output channels per workgroup; one stage =
+// conv3x3_patch_kernel's tile: kTM output pixels of one image x 64 output channels per workgroup; one stage =
 // the pixel patch of a 64-channel group (4 chunk planes of kPlaneSlots 16-byte slots) + that group's weights.
 constexpr int kTM = 448;                                // 28 fragments: 4 wave rows x 7
 constexpr int kPlaneSlots = 704;                        // >= (rows a tile touches + 2) * pitch + 2
@@ -353,7 +353,7 @@ struct ConvPrepArgs {
     int KH, KW, L, Lp;
     int n_interior, n_extra;
     uint32_t border_total, weight_total;   // border pixels of all images; dwords of packed weights
-    int64_t plane_stride;   // != 0: chunk-plane layout (Wp = row pitch), weights packed for conv3x3_planar_kernel
+    int64_t plane_stride;   // != 0: chunk-plane layout (Wp = row pitch), weights packed for conv3x3_patch_kernel
     int Cout;
     int sub, Ws, HWs;       // sub > 1: keep every sub-th pixel of every sub-th row of a Ws-wide source image
 };
@@ -975,8 +975,6 @@ struct PlanarArgs {
     uint32_t wo_magic;            // floor(2^32 / Wo) + 1
     uint32_t xp_bytes, wp_bytes;
     int wide16;                   // bf16 output: paired 16-byte stores (HoWo % 8 == 0, 16-byte aligned output)
-    int abl;                      // developer library only (timing; results are then wrong): bit 0 no output stores,
-                                  // bit 1 no patch fetch, bit 2 no MFMA loop
     // channels-last form (CL kernels): xp is the caller's [image][padded row][padded column][cin] activation and
     // out[b][y + border][x + border][channel] is addressed with these element strides
     int cin;
@@ -984,10 +982,13 @@ struct PlanarArgs {
     unsigned long long* stamps;   // developer library only: [workgroup][stage 0..7][8] shader-clock stamps, or null
 };
 
+// developer library: shader-clock stamps of the first eight stages of every workgroup (wave 0, lane 0)
 #ifdef MIQ_NO_DEV_SWITCHES
-#define MIQ_PLANAR_ABL(g, bit) false
+#define MIQ_PLANAR_STAMP(k)
 #else
-#define MIQ_PLANAR_ABL(g, bit) (((g).abl >> (bit)) & 1)
+#define MIQ_PLANAR_STAMP(k)                                                                         \
+    if (g.stamps && threadIdx.x == 0 && stamp_it < 8)                                               \
+        g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #endif
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 16] (the instruction takes an immediate).
@@ -1002,322 +1003,23 @@ __device__ __forceinline__ void wait_vmcnt_upto16(int n) {
     }
 }
 
+// One persistent workgroup per CU (eight waves, 256 registers each, all of the CU's LDS) walks (image, tile, channel
+// tile) units, with the phases of a stage overlapped in software:
+//   * LDS holds two stages (patch + weights): the fetch of stage s + 1 is issued piece by piece among the filter taps
+//     of stage s and lands under its MFMAs;
+//   * the fragments of filter tap t + 1 are read from LDS while the MFMAs of tap t run;
+//   * a finished unit's accumulators move to a second register set and leave, one fragment row per filter tap, among
+//     the MFMAs of the next unit's first stage: their conversion is VALU work beside the other wave's matrix
+//     instructions and their stores trickle out instead of queueing in one burst in front of the next fetch.
+// One barrier per stage.  A workgroup keeps one channel tile (the grid is a multiple of tiles_n), so its per-channel
+// epilogue parameters are loaded once, and with a single input-channel group its weights are too.
+// (Measured against two workgroups per CU at 128 registers, whose waves spent 12,500 cycles of a stage on fetch issue,
+// epilogue and barrier skew and 5,800 in the MFMA loop: 2-20 % faster for every output type and layout.)
+//
 // CL = channels-last activations in and out.  The patch is then gathered from pixel-major memory (a lane's 16 bytes are
 // chunk `plane` of its pixel, cin bytes apart from its neighbour's) into the same chunk planes, the weight fragment is
 // the MFMA's first operand, and its rows are read in an order that leaves a lane with eight consecutive output channels
 // of one pixel: one 8-byte store per fragment row for an int8 output.
-template <int OUT, bool STREAM, bool CL = false>
-__global__ __launch_bounds__(512, 4) void conv3x3_planar_kernel(PlanarArgs g) {   // 4 waves per SIMD: two workgroups per CU
-    constexpr int FM = 7, FN = 2;   // per wave: 7 pixel fragments x 2 channel fragments; waves 4 (pixels) x 2 (channels)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
-
-    struct Unit {
-        uint32_t b, p0, y0, tn;   // image, first output pixel of the tile, its row, channel tile
-    };
-    auto decode = [&](int unit) {
-        Unit u;
-        u.tn = static_cast<uint32_t>(unit % g.tiles_n);
-        const uint32_t t = static_cast<uint32_t>(unit / g.tiles_n);
-        u.b = t / g.tiles_img;
-        u.p0 = (t - u.b * g.tiles_img) * kTM;
-        u.y0 = u.p0 / g.Wo;
-        return u;
-    };
-
-    // One stage: 44 wave-instructions of patch (4 planes x 11 KiB) and 36 of weights, dealt over the waves.
-    auto issue = [&](const Unit& u, int cg, char* stage) {
-        const uint32_t first = (u.b * g.Hp + u.y0) * g.pitch;   // padded flat pixel the patch starts at
-        // (loops kept rolled: once per stage, and unrolled their wave-uniform addresses crowd the scalar registers)
-#pragma unroll 1
-        for (int q = wave; q < 44; q += 8) {
-            if (MIQ_PLANAR_ABL(g, 1)) break;
-            // channels-last: the four planes of a 64-pixel segment are read from the same cache lines, so they go out
-            // together (from four waves at once): issued plane by plane, a line has left the L1 before its next use
-            const int plane = CL ? (q & 3) : q / 11, seg = CL ? (q >> 2) : q - plane * 11;
-            // behind the rows the tile needs, the run continues into later rows (or past the buffer: zeros)
-            uint32_t off;
-            if constexpr (CL)
-                off = (first + seg * 64 + lane) * g.cin + (cg * 4 + plane) * kChunk;
-            else
-                off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
-            dma16(rx, stage + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
-        }
-#pragma unroll 1
-        for (int q = wave; q < 36; q += 8)
-            dma16(rw, stage + kPatchBytes + q * 1024, ((u.tn * g.ncg + cg) * 36 + q) * 1024 + lane * kChunk);
-    };
-
-    v4i acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
-
-    // Epilogue.  D[i][j]: i = 4*(lane>>4) + reg -> pixel, j = lane&15 -> output channel.  Returns the number
-    // of store instructions it issued (wave-uniform): the caller's counted vmcnt leaves exactly those in flight.
-    auto epilogue_nchw = [&](const Unit& u) -> int {
-        int issued = 0;
-        float al[FN], bi[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
-            al[j] = 1.f;
-            bi[j] = 0.f;
-            if constexpr (OUT != kOutI32) {
-                if (n < g.Cout) {
-                    al[j] = g.alpha[n];
-                    if (g.bias) bi[j] = g.bias[n];
-                }
-            }
-        }
-        // (opaque to the optimiser: otherwise it keeps a loop-invariant register per fragment, and spills)
-        uint32_t pfirst = u.p0 + wm * FM * 16 + (lane >> 4) * 4;
-        asm volatile("" : "+v"(pfirst));
-        constexpr int kPaired = OUT == kOutBF16 ? FM / 2 * 2 : 0;   // bf16: fragments (0,1), (2,3), (4,5) go out paired
-        if constexpr (OUT == kOutBF16) {
-            // as in the im2col-order kernel: two neighbouring pixel fragments trade 16-lane rows, and a lane
-            // stores eight consecutive pixels of its channel as one 16-byte vector
-            if (g.wide16) {
-                uint32_t ppair = u.p0 + wm * FM * 16 + paired_offset(lane);
-                asm volatile("" : "+v"(ppair));
-#pragma unroll
-                for (int i = 0; i < kPaired; i += 2) {
-                    const uint32_t p = ppair + i * 16;   // HoWo % 8 == 0: eight pixels in or out together
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
-                        uint2 h[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const v4i a = acc[i + e][j];
-                            acc[i + e][j] = v4i{0, 0, 0, 0};
-                            h[e] = pack4_bf16(dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
-                                              dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta));
-                        }
-                        const v4i v = pair_rows_bf16(h[0], h[1]);
-                        const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout;
-                        if (__ballot(mine) == 0) continue;
-                        ++issued;
-                        if (mine)
-                            *reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) +
-                                                    (static_cast<size_t>(u.b) * g.Cout + n) * g.HoWo + p) = v;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            if (OUT == kOutBF16 && i < kPaired && g.wide16) continue;   // stored above
-            const uint32_t p = pfirst + i * 16;   // HoWo % 4 == 0: four pixels in or out together
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
-                const v4i a = acc[i][j];
-                acc[i][j] = v4i{0, 0, 0, 0};
-                const bool mine = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout && !MIQ_PLANAR_ABL(g, 0);
-                if (__ballot(mine) == 0) continue;   // wave-uniform: no store instruction for this fragment
-                ++issued;
-                if (!mine) continue;
-                const size_t idx = (static_cast<size_t>(u.b) * g.Cout + n) * g.HoWo + p;
-                if constexpr (OUT == kOutI32) {
-                    v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
-                    if constexpr (STREAM) {
-                        __builtin_nontemporal_store(a, o);
-                    } else {
-                        *o = a;
-                    }
-                } else if constexpr (OUT == kOutF32) {
-                    const v4f v{dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
-                                dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta)};
-                    v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
-                    if constexpr (STREAM) {
-                        __builtin_nontemporal_store(v, o);
-                    } else {
-                        *o = v;
-                    }
-                } else {
-                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) =
-                        pack4_bf16(dequant1(a[0], bi[j], al[j], g.beta), dequant1(a[1], bi[j], al[j], g.beta),
-                                   dequant1(a[2], bi[j], al[j], g.beta), dequant1(a[3], bi[j], al[j], g.beta));
-                }
-            }
-        }
-        return issued;
-    };
-
-    // Channels-last epilogue.  D[i][j] with the operands swapped: row 4*(lane>>4) + reg -> output channel, column
-    // lane&15 -> pixel; with the weight rows read in the order below, fragments j = 0, 1 of a lane are channels
-    // n0 .. n0+3 and n0+4 .. n0+7.
-    auto epilogue_cl = [&](const Unit& u) -> int {
-        int issued = 0;
-        const int n0 = u.tn * 64 + wn * 32 + (lane >> 4) * 8;
-        float al[8], bi[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            al[c] = 1.f;
-            bi[c] = 0.f;
-        }
-        if constexpr (OUT != kOutI32) {
-            const v4f a0 = *reinterpret_cast<const v4f*>(g.alpha + n0), a1 = *reinterpret_cast<const v4f*>(g.alpha + n0 + 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                al[c] = a0[c];
-                al[c + 4] = a1[c];
-            }
-            if (g.bias) {
-                const v4f b0 = *reinterpret_cast<const v4f*>(g.bias + n0), b1 = *reinterpret_cast<const v4f*>(g.bias + n0 + 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bi[c] = b0[c];
-                    bi[c + 4] = b1[c];
-                }
-            }
-        }
-        uint32_t pfirst = u.p0 + wm * FM * 16 + (lane & 15);
-        asm volatile("" : "+v"(pfirst));
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const uint32_t p = pfirst + i * 16;
-            const v4i a0 = acc[i][0], a1 = acc[i][1];
-            acc[i][0] = v4i{0, 0, 0, 0};
-            acc[i][1] = v4i{0, 0, 0, 0};
-            const bool mine = p < static_cast<uint32_t>(g.HoWo) && !MIQ_PLANAR_ABL(g, 0);
-            if (__ballot(mine) == 0) continue;   // wave-uniform
-            issued += (OUT == kOutI32 || OUT == kOutF32) ? 2 : 1;
-            if (!mine) continue;
-            const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
-            const size_t idx = static_cast<size_t>(u.b) * g.o_img + static_cast<size_t>(y) * g.o_row + x * g.o_pix + g.o_off + n0;
-            if constexpr (OUT == kOutI32) {
-                v4i* o = reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx);
-                o[0] = a0;
-                o[1] = a1;
-            } else {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    v[c] = dequant1(a0[c], bi[c], al[c], g.beta);
-                    v[c + 4] = dequant1(a1[c], bi[c + 4], al[c + 4], g.beta);
-                }
-                if constexpr (OUT == kOutF32) {
-                    v4f* o = reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx);
-                    o[0] = v4f{v[0], v[1], v[2], v[3]};
-                    o[1] = v4f{v[4], v[5], v[6], v[7]};
-                } else if constexpr (OUT == kOutBF16) {
-                    const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
-                    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(g.out) + idx) = uint4{lo.x, lo.y, hi.x, hi.y};
-                } else {
-                    *reinterpret_cast<uint2*>(static_cast<int8_t*>(g.out) + idx) =
-                        uint2{requant4_i8(v[0], v[1], v[2], v[3]), requant4_i8(v[4], v[5], v[6], v[7])};
-                }
-            }
-        }
-        return issued;
-    };
-    auto epilogue = [&](const Unit& u) -> int {
-        if constexpr (CL)
-            return epilogue_cl(u);
-        else
-            return epilogue_nchw(u);
-    };
-
-    // weight row of this lane inside a tap's [chunk][channel][16 B] block; fragment j is kWFrag bytes further
-    const int w_lane = CL ? ((lane >> 4) * 64 + wn * 32 + ((lane & 15) >> 2) * 8 + (lane & 3)) * kChunk
-                          : ((lane >> 4) * 64 + wn * 32 + (lane & 15)) * kChunk;
-    constexpr int kWFrag = CL ? 4 * kChunk : 16 * kChunk;
-
-#ifndef MIQ_NO_DEV_SWITCHES
-    int stamp_it = 0;   // developer library: shader-clock stamps of the first eight stages of every workgroup
-#define MIQ_PLANAR_STAMP(k)                                                                         \
-    if (g.stamps && threadIdx.x == 0 && stamp_it < 8)                                               \
-        g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime();
-#else
-#define MIQ_PLANAR_STAMP(k)
-#endif
-    bool pending = false;   // the previous unit's accumulators wait to be stored
-    Unit prev{};
-    for (int unit = blockIdx.x; unit < g.units; unit += gridDim.x) {
-        const Unit u = decode(unit);
-        // patch address of each fragment row this lane supplies: plane lane>>4, pixel (y - y0) * pitch + x
-        int aoff[FM];
-        uint32_t qfirst = u.p0 + wm * FM * 16 + (lane & 15);
-        asm volatile("" : "+v"(qfirst));
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            uint32_t p = qfirst + i * 16;
-            if (p >= static_cast<uint32_t>(g.HoWo)) p = g.HoWo - 1;   // rows past the image: computed, never stored
-            const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
-            aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + ((y - u.y0) * g.pitch + x) * kChunk;
-        }
-        for (int cg = 0; cg < g.ncg; ++cg) {
-            MIQ_PLANAR_STAMP(0)
-            issue(u, cg, smem);
-            MIQ_PLANAR_STAMP(1)
-            int stores = 0;
-            if (pending) {   // the previous unit's stores go out under this stage's fetch
-                stores = epilogue(prev);
-                pending = false;
-            }
-            MIQ_PLANAR_STAMP(2)
-            // The stage has landed once all but the `stores` youngest operations are done (vector memory
-            // operations retire in issue order): the stores themselves are not waited for, so they drain
-            // under the MFMAs below instead of holding the workgroup until memory has taken them.
-            wait_vmcnt_upto16(stores);
-            MIQ_PLANAR_STAMP(3)
-            __syncthreads();
-            MIQ_PLANAR_STAMP(4)
-            // One filter row per iteration, kept as a loop: unrolled over all nine taps the compiler
-            // prefetches fragments across taps and spills at the 128 registers two workgroups per CU allow;
-            // four waves per SIMD hide the fragment reads instead.
-#pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh) {
-                if (MIQ_PLANAR_ABL(g, 2)) break;
-                const char* arow = smem + kh * g.pitch * kChunk;
-                const char* wrow = smem + kPatchBytes + kh * (3 * 4096) + w_lane;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    v4i wf[FN];
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) wf[j] = lds_read16(wrow + kw * 4096 + j * kWFrag);
-                    v4i af[FM];
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) af[i] = lds_read16(arow + aoff[i] + kw * kChunk);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            acc[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
-                }
-            }
-            MIQ_PLANAR_STAMP(5)
-            __syncthreads();   // the stage is read: the next one may overwrite it
-            MIQ_PLANAR_STAMP(6)
-#ifndef MIQ_NO_DEV_SWITCHES
-            ++stamp_it;
-#endif
-        }
-        prev = u;
-        pending = true;
-    }
-    if (pending) (void)epilogue(prev);
-}
-
-
-// The same convolution with ONE workgroup per CU (256 registers a wave) and the phases of a stage overlapped in
-// software instead of across two workgroups, which at two waves per SIMD each spent most of a stage outside its MFMA
-// loop (shader-clock stamps: fetch issue + epilogue + barrier skew 12,500 cycles against 5,800 in the loop):
-//   * LDS holds two stages: the fetch of stage s + 1 is issued at the top of stage s and lands under its MFMAs;
-//   * the fragments of filter tap t + 1 are read from LDS while the MFMAs of tap t run;
-//   * a finished unit's accumulators move to a second register set and leave, one fragment row per filter tap, among
-//     the MFMAs of the next unit's first stage: their conversion is VALU work between matrix instructions and their
-//     stores trickle out instead of queueing in one burst in front of the next fetch.
-// One barrier per stage.  A workgroup keeps one channel tile (the grid is a multiple of tiles_n), so its per-channel
-// epilogue parameters are loaded once, and with a single input-channel group its weights are too.
 template <int OUT, bool STREAM, bool CL>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     constexpr int FM = 7, FN = 2;
@@ -1644,18 +1346,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
 
 template <int OUT, bool CL = false>
 int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
-    const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 2 = the two-workgroups-per-CU kernel
-    if (sw && sw[0] == '2') {
-        void (*kern)(PlanarArgs) = conv3x3_planar_kernel<OUT, false, CL>;
-        if constexpr (!CL) {
-            if (stream_out) kern = conv3x3_planar_kernel<OUT, true>;
-        }
-        constexpr int kLds = kPlanarStage;
-        if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
-        const int grid = g.units < 512 ? g.units : 512;   // two persistent workgroups per CU
-        kern<<<grid, 512, kLds, st>>>(g);
-        return check_launch("conv3x3_planar_kernel");
-    }
     void (*kern)(PlanarArgs) = conv3x3_patch_kernel<OUT, false, CL>;
     if constexpr (!CL) {
         if (stream_out) kern = conv3x3_patch_kernel<OUT, true, false>;
@@ -1886,7 +1576,6 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
         pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)G.wp_bytes;
         pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
-        if (const char* abl = dev_switch("MIQ_PLANAR_ABL")) pa.abl = atoi(abl);   // developer library: timing ablations
         if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
             pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
         const int64_t units = B * pa.tiles_img * pa.tiles_n;
@@ -1942,7 +1631,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
 
 // ---- channels-last entry points ---------------------------------------------------------------------
 // The packed weight of the channels-last entry point: the im2col-order form wp[Cout][KH][Lp] and, for 3 x 3 filters over
-// whole 64-channel groups, behind it (at the next multiple of 256 bytes) the form conv3x3_planar_kernel stages from.
+// whole 64-channel groups, behind it (at the next multiple of 256 bytes) the form conv3x3_patch_kernel stages from.
 struct PackedWeight {
     int64_t rows_bytes;     // the im2col-order form
     int64_t planar_at;      // offset of the patch kernel's form; 0 = none
@@ -2038,7 +1727,6 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
             pa.cin = (int)Cin;
             pa.o_pix = (int)Cout; pa.o_row = (int)(Wop * Cout); pa.o_img = (int)(Hop * Wop * Cout);
             pa.o_off = (int)((out_pad * Wop + out_pad) * Cout);
-            if (const char* abl = dev_switch("MIQ_PLANAR_ABL")) pa.abl = atoi(abl);
             if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
                 pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
             const int64_t units = B * pa.tiles_img * pa.tiles_n;

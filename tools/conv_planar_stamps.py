@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a workgroup of the 3x3 / stride 1 patch kernel spends a stage: shader-clock stamps of the developer library
 (MIQ_PLANAR_STAMPS) on ResNet-18's 64->64 56x56 and 128->128 28x28 layers at batch 256; medians over the workgroups, in
-cycles: issue of the fetch | epilogue of the previous unit | wait for the fetch | barrier | MFMA loop | barrier.
+cycles: wait for the stage's fetch | barrier | decode of the next stage | the nine taps (with the next fetch's pieces and,
+where a unit has just finished, its rows leaving among them).
 
     python tools/conv_planar_stamps.py [out: i32|f32|bf16|i8] [cl]"""
 import os
@@ -37,8 +38,7 @@ for C, H, Co in [(64, 56, 64), (128, 28, 128)]:
     torch.cuda.synchronize()
     del os.environ["MIQ_PLANAR_STAMPS"]
     t = stamps.view(512, 8, 8).cpu()
-    two = os.environ.get("MIQ_CONV_PLANAR") == "2"   # the two-workgroups-per-CU kernel; else the one-workgroup kernel
-    names = ["issue", "epilogue", "wait", "barrier", "mfma", "barrier"] if two else ["wait", "barrier", "issue", "taps", "-", "-"]
+    names = ["wait", "barrier", "next", "taps", "-", "-"]
     print(f"{C}->{Co} {H}x{H} ({'channels-last' if cl else 'NCHW'}, {sys.argv[1] if len(sys.argv) > 1 else 'i32'} out)")
     for it in range(8):
         ok = t[:, it, 6] > 0
@@ -50,7 +50,7 @@ for C, H, Co in [(64, 56, 64), (128, 28, 128)]:
               f" | whole {int(tot.median()):6d}")
     ok = t[:, 0, 0] > 0
     life = []
-    for wg in range(512 if two else 256):
+    for wg in range(256):
         last = max(int(t[wg, it, 6]) for it in range(8))
         if last:
             life.append(last - int(t[wg, 0, 0]))
