@@ -1359,6 +1359,210 @@ int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
     return check_launch("conv3x3_patch_kernel");
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Stems: at most four input channels (one pixel = 4 bytes of the padded channels-last copy), five to eight filter
+// columns, stride 2 (ResNet's 3 -> 64 7 x 7 / 2).  In im2col order such a layer's K axis is short (KH rows of 32 bytes)
+// and its M axis enormous, and the im2col-order kernel fetches every input byte about twelve times from the L2
+// (1 GB for a 54 MB input).  Here a workgroup owns a 16 x 16 block of output pixels x 64 channels and stages the input
+// patch those pixels see once (38 rows of 40 pixels at most, 6 KB) together with the channel tile's filters (16 KB);
+// the im2col expansion happens on the way from LDS to registers: the K chunk c = 2 * kh + half of output pixel (y, x)
+// is the 16 bytes at patch pixel (2y + kh, 2x + 4 * half), read as two 8-byte halves (the address is only 8-byte
+// aligned).  Four waves, wave w multiplies output rows 4w .. 4w+3 (four fragments of 16 pixels) by all 64 channels.
+// Chunks past the filter's last row meet zero weights.  Channels-last in and out; the weight fragment is the MFMA's
+// first operand and the filters sit in LDS in an order that leaves a lane with sixteen consecutive channels of one
+// pixel (one 16-byte store per pixel at int8).  Measured on ResNet-18's first layer at batch 256 (tools/conv_stem_ab.py):
+// int8 out 235 -> 79 us, bf16 221 -> 117, fp32 329 -> 262; with int32 out (and for NCHW outputs, whose 16 x 16 blocks
+// write 64-byte runs) the im2col-order kernel's long output runs win and it keeps those.
+struct StemArgs {
+    const int8_t* xp;
+    const int8_t* wp;
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int Cout, KH, Kp;   // Kp = KH * 32: bytes of one channel's packed filter
+    int Hp, Wp, Ho, Wo;
+    int tiles_x, tiles_y, tiles_n, units;
+    uint32_t xp_bytes, wp_bytes;
+    int o_img, o_row, o_pix, o_off;   // channels-last output: element strides of out[b][y + border][x + border][channel]
+};
+constexpr int kStemPitch = 40;                        // patch pixels per row: 15 * 2 + 8 = 38, rounded to 16 bytes
+constexpr int kStemPatchBytes = 6 * 1024;             // 38 rows x 160 bytes = 6080, fetched as six wave-instructions
+constexpr int kStemWeightBytes = 16 * 64 * kChunk;    // [chunk][channel][16 B]
+
+template <int OUT>
+__global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs g) {
+    // Persistent workgroups: the channel tile's filters are fetched once, the patches alternate between two buffers and
+    // the next block's patch is on its way while this one is multiplied and stored.
+    __shared__ __attribute__((aligned(16))) char smem[2 * kStemPatchBytes + kStemWeightBytes + 512];
+    char* const wst = smem + 2 * kStemPatchBytes;
+    float* const params = reinterpret_cast<float*>(wst + kStemWeightBytes);   // alpha[64], bias[64] of the channel tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int tn = static_cast<int>(blockIdx.x) % g.tiles_n;   // the grid is a multiple of tiles_n: one channel tile per workgroup
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+    struct Block {
+        int x0, y0;
+        uint32_t b;
+    };
+    auto decode = [&](uint32_t unit) {
+        Block k;
+        uint32_t t = unit / g.tiles_n;
+        k.x0 = (t % g.tiles_x) * 16;
+        t /= g.tiles_x;
+        k.y0 = (t % g.tiles_y) * 16;
+        k.b = t / g.tiles_y;
+        return k;
+    };
+    // patch: rows 2*y0 .. 2*y0 + 29 + KH of the image, 160 bytes from pixel 2*x0 (a run that leaves the row continues
+    // into the next one, one that leaves the buffer reads zeros: both only under pixels that are never stored)
+    const int pieces = (30 + g.KH) * 10;
+    auto fetch_patch = [&](const Block& k, char* patch) {
+        for (int i = wave; i * 64 < pieces; i += 4) {
+            const int id = i * 64 + lane, row = id / 10, ch = id - row * 10;
+            const uint32_t off = id < pieces ? ((k.b * g.Hp + k.y0 * 2 + row) * g.Wp + k.x0 * 2) * 4 + ch * kChunk : kOob;
+            dma16(rx, patch + i * 1024, off);
+        }
+    };
+    {
+        // filters: chunk c of the 64 channels as one wave-instruction; position l of a chunk holds the channel that
+        // leaves lane group l>>2 & 3 with sixteen consecutive channels (epilogue below)
+        const int ch = ((lane & 15) >> 2) * 16 + (lane >> 4) * 4 + (lane & 3);
+        const int n = tn * 64 + ch;
+#pragma unroll
+        for (int c = wave; c < 16; c += 4)
+            dma16(rw, wst + c * 1024, (c < g.KH * 2 && n < g.Cout) ? static_cast<uint32_t>(n) * g.Kp + c * kChunk : kOob);
+    }
+    // per-channel epilogue parameters of the channel tile, once, in LDS (in registers they cost a third of the budget)
+    if constexpr (OUT != kOutI32) {
+        if (threadIdx.x < 128) {
+            const int c = threadIdx.x & 63, n = tn * 64 + c;
+            float v = threadIdx.x < 64 ? 1.f : 0.f;
+            if (n < g.Cout) {
+                if (threadIdx.x < 64)
+                    v = g.alpha[n];
+                else if (g.bias)
+                    v = g.bias[n];
+            }
+            params[threadIdx.x] = v;
+        }
+    }
+    const v2f beta2{g.beta, g.beta};
+
+    uint32_t unit = blockIdx.x;
+    const uint32_t units = static_cast<uint32_t>(g.units);
+    Block cur = decode(unit);
+    fetch_patch(cur, smem);
+    const int ksteps = (g.KH * 2 + 3) >> 2;
+    const char* w_lane = wst + (q * 64 + r) * kChunk;
+    // this lane's patch offset for fragment row 0 and K step 0: filter row q>>1, half q&1, output column r
+    const int a_off = (((wave * 4 * 2 + (q >> 1)) * kStemPitch) + (q & 1) * 4 + r * 2) * 4;
+    int buf = 0;
+    int stores = 0;   // store instructions this wave issued behind the fetch of the patch about to be read
+    for (; unit < units; unit += gridDim.x) {
+        // Vector memory operations retire in issue order: once all but the stores issued after it are done, this wave's
+        // pieces of the patch have landed, and the stores go on draining under the next block's arithmetic.
+        wait_vmcnt_upto16(stores);
+        __syncthreads();   // every wave's pieces have landed; every wave has left the buffer the next fetch overwrites
+        {
+            // rows of this wave inside the image x store instructions per row (wave-uniform: lane 0 always stores)
+            const int rows = min(4, max(0, g.Ho - (cur.y0 + wave * 4)));
+            stores = rows * (OUT == kOutI8 ? 1 : OUT == kOutBF16 ? 2 : 4);
+        }
+        const uint32_t nunit = unit + gridDim.x;
+        const Block nxt = decode(nunit < units ? nunit : unit);
+        if (nunit < units) fetch_patch(nxt, smem + (buf ^ 1) * kStemPatchBytes);
+
+        v4i acc[4][4];
+        const char* a_lane = smem + buf * kStemPatchBytes + a_off;
+        auto kstep = [&](int j, auto FIRST) {   // FIRST: the accumulators start from this step's products, not from zeros
+            v4i af[4], wf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = lds_read16(w_lane + j * 4096 + f * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const char* a = a_lane + (i * 2 + j * 2) * (kStemPitch * 4);
+                const v2u lo = *reinterpret_cast<const v2u*>(a), hi = *reinterpret_cast<const v2u*>(a + 8);
+                af[i] = v4i{(int)lo[0], (int)lo[1], (int)hi[0], (int)hi[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const v4i c = decltype(FIRST)::value ? v4i{0, 0, 0, 0} : acc[i][f];
+                    acc[i][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[f], af[i], c, 0, 0, 0);
+                }
+        };
+        kstep(0, std::true_type{});
+        for (int j = 1; j < ksteps; ++j) kstep(j, std::false_type{});
+
+        // D[R][c] of fragment f: R = 4*(lane>>4) + reg -> channel (lane>>4)*16 + f*4 + reg of the tile, c = lane&15 -> pixel
+        const int n0 = tn * 64 + q * 16;
+        const int x = cur.x0 + r;
+        if (x < g.Wo && n0 < g.Cout) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = cur.y0 + wave * 4 + i;
+                if (y >= g.Ho) continue;
+                const size_t idx = static_cast<size_t>(cur.b) * g.o_img + static_cast<size_t>(y) * g.o_row + x * g.o_pix + g.o_off + n0;
+                uint32_t packed[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const v4i a = acc[i][f];
+                    if constexpr (OUT == kOutI32) {
+                        reinterpret_cast<v4i*>(static_cast<int*>(g.out) + idx)[f] = a;
+                    } else {
+                        const v4f al = *reinterpret_cast<const v4f*>(params + q * 16 + f * 4);
+                        const v4f bi = *reinterpret_cast<const v4f*>(params + 64 + q * 16 + f * 4);
+                        const v2f lo = dequant2(a[0], a[1], v2f{bi[0], bi[1]}, v2f{al[0], al[1]}, beta2);
+                        const v2f hi = dequant2(a[2], a[3], v2f{bi[2], bi[3]}, v2f{al[2], al[3]}, beta2);
+                        if constexpr (OUT == kOutF32)
+                            reinterpret_cast<v4f*>(static_cast<float*>(g.out) + idx)[f] = v4f{lo[0], lo[1], hi[0], hi[1]};
+                        else if constexpr (OUT == kOutBF16) {
+                            const uint2 h = pack4_bf16(lo[0], lo[1], hi[0], hi[1]);
+                            if (f & 1)
+                                reinterpret_cast<uint4*>(static_cast<uint16_t*>(g.out) + idx)[f >> 1] = uint4{packed[0], packed[1], h.x, h.y};
+                            packed[0] = h.x;
+                            packed[1] = h.y;
+                        } else {
+                            packed[f] = requant4_i8(lo[0], lo[1], hi[0], hi[1]);
+                        }
+                    }
+                }
+                if constexpr (OUT == kOutI8)
+                    *reinterpret_cast<uint4*>(static_cast<int8_t*>(g.out) + idx) = uint4{packed[0], packed[1], packed[2], packed[3]};
+            }
+        }
+        cur = nxt;
+        buf ^= 1;
+    }
+}
+
+// The stem kernel serves: one 4-byte pixel (Cin <= 4), 5 to 8 filter columns (32-byte filter rows), at most 8 filter rows,
+// stride 2, no subsampling re-layout.
+inline bool stem_shape(const ConvGeom& G) {
+    return G.Cp == 4 && G.Lp == 32 && G.KH <= 8 && G.stride == 2 && G.sub == 1 && !G.planar && G.Ho > 0 && G.Wo > 0;
+}
+
+template <int OUT>
+int launch_stem(StemArgs g, int64_t B, hipStream_t st) {
+    g.tiles_x = (g.Wo + 15) / 16;
+    g.tiles_y = (g.Ho + 15) / 16;
+    g.tiles_n = (g.Cout + 63) / 64;
+    const int64_t units = B * g.tiles_y * g.tiles_x * g.tiles_n;
+    MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_nhwc: too many tiles");
+    g.units = static_cast<int>(units);
+    // persistent: up to five workgroups per CU (29 KB of LDS each), a multiple of the channel tiles
+    int64_t grid = std::min<int64_t>(units, 1280);
+    if (grid > g.tiles_n) grid -= grid % g.tiles_n;
+    conv_stem_kernel<OUT><<<static_cast<unsigned>(grid), 256, 0, st>>>(g);
+    return check_launch("conv_stem_kernel");
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool CL = false>
 int launch_tile(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
@@ -1738,6 +1942,22 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
                 case MIQ_I32: return launch_planar<kOutI32, true>(pa, false, st);
                 default: return launch_planar<kOutI8, true>(pa, false, st);
             }
+        }
+    }
+
+    if (stem_shape(G) && out_dtype != MIQ_I32 && Cout % 16 == 0 && miq::aligned(out, 16) && miq::aligned(alpha, 16) && miq::aligned(bias, 16) &&
+        !(dev_switch("MIQ_CONV_STEM") && dev_switch("MIQ_CONV_STEM")[0] == '0')) {
+        StemArgs sa{};
+        sa.xp = x; sa.wp = wp; sa.bias = bias; sa.alpha = alpha; sa.out = out; sa.beta = beta;
+        sa.Cout = (int)Cout; sa.KH = (int)KH; sa.Kp = (int)G.Kp;
+        sa.Hp = (int)G.Hp; sa.Wp = (int)G.Wp; sa.Ho = (int)G.Ho; sa.Wo = (int)G.Wo;
+        sa.xp_bytes = (uint32_t)G.xp_bytes; sa.wp_bytes = (uint32_t)G.wp_bytes;
+        sa.o_pix = (int)Cout; sa.o_row = (int)(Wop * Cout); sa.o_img = (int)(Hop * Wop * Cout);
+        sa.o_off = (int)((out_pad * Wop + out_pad) * Cout);
+        switch (out_dtype) {
+            case MIQ_F32: return launch_stem<kOutF32>(sa, B, st);
+            case MIQ_BF16: return launch_stem<kOutBF16>(sa, B, st);
+            default: return launch_stem<kOutI8>(sa, B, st);
         }
     }
 

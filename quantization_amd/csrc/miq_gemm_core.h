@@ -106,15 +106,18 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 // Clamping first (the bounds are integers, so the order does not matter) lets one addition do the rounding and the
 // conversion: y + 1.5 * 2^23 has an ulp of 1, so the sum is rounded half-even to an integer whose two's complement low
 // byte sits in the low byte of the float's mantissa.  Three byte permutes then pack four of them.
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t requant4_i8(float a, float b, float c, float d) {
-    auto q = [](float y) { return __float_as_uint(__fadd_rn(__builtin_amdgcn_fmed3f(y, -128.0f, 127.0f), 12582912.0f)); };
-    const uint32_t lo = __builtin_amdgcn_perm(q(b), q(a), 0x0c0c0400u);   // a.b0, b.b0, 0, 0
-    const uint32_t hi = __builtin_amdgcn_perm(q(d), q(c), 0x04000c0cu);   // 0, 0, c.b0, d.b0
+#pragma clang fp contract(off)
+    auto clamp = [](float y) { return __builtin_amdgcn_fmed3f(y, -128.0f, 127.0f); };
+    const v2f magic{12582912.0f, 12582912.0f};
+    const v2f lo2 = v2f{clamp(a), clamp(b)} + magic, hi2 = v2f{clamp(c), clamp(d)} + magic;   // two packed additions
+    const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(lo2[1]), __float_as_uint(lo2[0]), 0x0c0c0400u);   // a.b0, b.b0, 0, 0
+    const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(hi2[1]), __float_as_uint(hi2[0]), 0x04000c0cu);   // 0, 0, c.b0, d.b0
     return lo | hi;
 }
 
 // dequant1 on two values at once, as packed fp32 instructions (one rounding per step, no contraction).
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f dequant2(int a, int b, v2f bias, v2f alpha, v2f beta) {
 #pragma clang fp contract(off)
     v2f t{static_cast<float>(a), static_cast<float>(b)};

@@ -273,6 +273,8 @@ CONV_SHAPES = [
     # from aligned 8-byte runs; odd sizes, ragged channels, stride 3 and a 3-channel image by single bytes)
     (2, 64, 16, 16, 128, 1, 2, 0), (3, 70, 24, 40, 20, 1, 2, 0), (2, 16, 15, 17, 8, 1, 2, 0),
     (2, 32, 13, 13, 8, 1, 3, 0), (1, 3, 9, 9, 4, 1, 2, 0), (2, 8, 12, 20, 8, 1, 2, 0), (2, 128, 56, 56, 64, 1, 2, 0),
+    # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
+    (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
 ]
 
 

@@ -20,7 +20,9 @@ w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device="cuda").to
 alpha = torch.rand(Co, device="cuda") * 0.01
 Ho = (H + 2 * p - k) // s + 1
 if cl:
-    xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, p, p, p, p)).contiguous()
+    cpad = (-C) % 4   # the channels-last entry point takes whole 4-byte pixels
+    xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, cpad, p, p, p, p)).contiguous()
+    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cpad)).contiguous()
     wp = N.conv2d_i8_pack_weight(w)
     outs = [torch.zeros(B, Ho + 2, Ho + 2, Co, dtype=od, device="cuda") for _ in range(3)]
     for i in range(iters):
