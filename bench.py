@@ -63,6 +63,23 @@ def median_ms(fn, iters=30, warm=20):
     return ts[len(ts) // 2]
 
 
+def graphed_ms(step, steps, reps=20, warm=20):
+    """Milliseconds per step of `steps` consecutive steps captured once into a HIP graph and replayed: device time of
+    launch-bound sequences (a decode step is three 12-microsecond kernels; enqueued call by call from Python, the
+    interval between two events measures the host).  Median over `reps` replays."""
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(steps):
+            step()
+    graph.replay()
+    torch.cuda.synchronize()
+    ts = sorted(event_times(graph.replay, reps))
+    return ts[len(ts) // 2] / steps
+
+
 def kernel_source_sha():
     """Digest of the GEMM kernel's sources: counter results under profiles/ are stamped with it."""
     h = hashlib.sha256()
@@ -106,7 +123,8 @@ def weight_only_float(N_, dev):
     # Infinity Cache, so the decode sizes are priced on bytes that do come from HBM
     ws = [torch.randint(-128, 128, (Nn, K), dtype=torch.int32, device=dev).to(torch.int8) for _ in range(10)]
     alpha = torch.rand(Nn, device=dev) * 0.01
-    res = {"weight": f"int8 [{Nn},{K}], 10 copies in turn", "out_dtype": "float32"}
+    res = {"weight": f"int8 [{Nn},{K}], 10 copies in turn", "out_dtype": "float32",
+           "timing": "HIP graph of 40 calls, replayed (call_ms); call by call from Python beside it"}
     for M, dt in ((16, torch.bfloat16), (16, torch.float32), (256, torch.bfloat16), (256, torch.float32)):
         x = torch.randn(M, K, device=dev).to(dt)
         out = torch.empty(M, Nn, device=dev)
@@ -115,9 +133,11 @@ def weight_only_float(N_, dev):
         def call():
             it[0] += 1
             N_.gemm_w8(x, ws[it[0] % 10], alpha=alpha, out=out)
-        ms = median_ms(call, 50, 50)
+        eager = median_ms(call, 50, 50)
+        ms = graphed_ms(call, 40)   # forty calls = four passes over the ten weights, as one graph
         nbytes = Nn * K + M * K * x.element_size() + M * Nn * 4
-        entry = {"call_ms": round(ms, 4), "weight_GBps": round(Nn * K / (ms * 1e-3) / 1e9, 1),
+        entry = {"call_ms": round(ms, 4), "call_ms_enqueued_from_python": round(eager, 4),
+                 "weight_GBps": round(Nn * K / (ms * 1e-3) / 1e9, 1),
                  "TFLOPs": round(2.0 * M * Nn * K / (ms * 1e-3) / 1e12, 1)}
         if M <= 16:
             entry["roofline"] = hbm_roofline(nbytes, ms)
@@ -128,28 +148,43 @@ def weight_only_float(N_, dev):
 def llama8b_mlp_decode(N_, dev):
     """BASELINE config 4 at one token: the three int8 matmuls of a Llama-3-8B MLP (gate, up [14336,4096]; down
     [4096,14336]) with the fused dequant epilogue, M = 1 and M = 16, fp32 out.  A step is bound by reading the
-    three int8 weights once: algorithmic bytes = 3 * 14336 * 4096 + activations + outputs."""
-    shapes = (("gate", 14336, 4096), ("up", 14336, 4096), ("down", 4096, 14336))
+    three int8 weights once: algorithmic bytes = 3 * 14336 * 4096 + activations + outputs.  `fused_gate_up` is the
+    same step with gate and up stored as one [28672,4096] weight (they multiply the same activations): two launches."""
     layers = 4   # four layers' weights (705 MB) taken in turn: every step streams its weights from HBM, not from the Infinity Cache
-    ws = [{n: (torch.randint(-128, 128, (r, c), dtype=torch.int32, device=dev).to(torch.int8),
-               torch.rand(r, device=dev) * 0.01) for n, r, c in shapes} for _ in range(layers)]
-    res = {"weights": f"int8 gate/up [14336,4096], down [4096,14336], {layers} layers in turn", "out_dtype": "float32"}
+    ws = []
+    for _ in range(layers):
+        gu = torch.randint(-128, 128, (28672, 4096), dtype=torch.int32, device=dev).to(torch.int8)
+        ws.append({"gate_up": gu, "gate": gu[:14336], "up": gu[14336:], "a_gu": torch.rand(28672, device=dev) * 0.01,
+                   "down": torch.randint(-128, 128, (4096, 14336), dtype=torch.int32, device=dev).to(torch.int8),
+                   "a_down": torch.rand(4096, device=dev) * 0.01})
+    res = {"weights": f"int8 gate/up [14336,4096], down [4096,14336], {layers} layers in turn", "out_dtype": "float32",
+           "timing": f"HIP graph of {5 * layers} steps, replayed (step_ms); call by call from Python beside it"}
     for M in (1, 16):
         xa = torch.randint(-128, 128, (M, 4096), dtype=torch.int32, device=dev).to(torch.int8)
         xd = torch.randint(-128, 128, (M, 14336), dtype=torch.int32, device=dev).to(torch.int8)
-        outs = {n: torch.empty(M, r, device=dev) for n, r, c in shapes}
-
+        o_gu, o_down = torch.empty(M, 28672, device=dev), torch.empty(M, 4096, device=dev)
+        o_g, o_u = torch.empty(M, 14336, device=dev), torch.empty(M, 14336, device=dev)
         it = [0]
 
         def step():
             it[0] += 1
-            layer = ws[it[0] % layers]
-            for n, r, c in shapes:
-                N_.gemm_i8(xd if n == "down" else xa, layer[n][0], alpha=layer[n][1], out=outs[n])
-        ms = median_ms(step, 50, 50)
-        nbytes = sum(r * c + M * c + 4 * M * r for _, r, c in shapes)
-        res[f"M{M}"] = {"step_ms": round(ms, 4), "weight_GBps": round(3 * 14336 * 4096 / (ms * 1e-3) / 1e9, 1),
-                        "roofline": hbm_roofline(nbytes, ms)}
+            w = ws[it[0] % layers]
+            N_.gemm_i8(xa, w["gate"], alpha=w["a_gu"][:14336], out=o_g)
+            N_.gemm_i8(xa, w["up"], alpha=w["a_gu"][14336:], out=o_u)
+            N_.gemm_i8(xd, w["down"], alpha=w["a_down"], out=o_down)
+
+        def step_fused():
+            it[0] += 1
+            w = ws[it[0] % layers]
+            N_.gemm_i8(xa, w["gate_up"], alpha=w["a_gu"], out=o_gu)
+            N_.gemm_i8(xd, w["down"], alpha=w["a_down"], out=o_down)
+        eager = median_ms(step, 50, 50)
+        ms = graphed_ms(step, 5 * layers)   # five passes over the layers' weights as one graph
+        fused = graphed_ms(step_fused, 5 * layers)
+        nbytes = 3 * 14336 * 4096 + M * (2 * 4096 + 14336) + 4 * M * (2 * 14336 + 4096)
+        res[f"M{M}"] = {"step_ms": round(ms, 4), "step_ms_enqueued_from_python": round(eager, 4),
+                        "weight_GBps": round(3 * 14336 * 4096 / (ms * 1e-3) / 1e9, 1), "roofline": hbm_roofline(nbytes, ms),
+                        "fused_gate_up": {"step_ms": round(fused, 4), "roofline": hbm_roofline(nbytes - M * 4096, fused)}}
     return res
 
 
