@@ -980,7 +980,20 @@ struct PlanarArgs {
     int cin;
     int o_img, o_row, o_pix, o_off;
     unsigned long long* stamps;   // developer library only: [workgroup][stage 0..7][8] shader-clock stamps, or null
+    // NCHW activation staged directly (DIRECT kernels): x[B][cin][H][W], W % 4 == 0
+    const int8_t* x;
+    uint32_t x_bytes;
+    int H, W, pad;
+    int rows;                     // patch rows staged per unit (the most a tile touches)
+    int part_rows;                // ceil(rows / 12): rows one wave re-lays per piece
+    int w4;                       // W / 4
+    int cpc;                      // 16-byte chunks that cover a run of part_rows * W bytes starting anywhere in a chunk
+    uint32_t w4_magic, cpc_magic; // floor(2^32 / d) + 1 for d = w4 and d = cpc
 };
+
+// DIRECT kernels: slots per chunk plane of the LDS patch, and the per-wave staging area for raw NCHW bytes
+constexpr int kDirectSlots = 592;
+constexpr int kDirectStageBytes = 1792;   // 16 channels x cpc chunks of one wave (cpc <= 7)
 
 // developer library: shader-clock stamps of the first eight stages of every workgroup (wave 0, lane 0)
 #ifdef MIQ_NO_DEV_SWITCHES
@@ -1020,10 +1033,21 @@ __device__ __forceinline__ void wait_vmcnt_upto16(int n) {
 // chunk `plane` of its pixel, cin bytes apart from its neighbour's) into the same chunk planes, the weight fragment is
 // the MFMA's first operand, and its rows are read in an order that leaves a lane with eight consecutive output channels
 // of one pixel: one 8-byte store per fragment row for an int8 output.
-template <int OUT, bool STREAM, bool CL>
+//
+// DIRECT = the NCHW activation itself is the source (no re-layout launch, no padded copy; W % 4 == 0).  The raw bytes of
+// a stage reach LDS by LDS-DMA in six pieces issued among taps 0-5: in a piece a wave fetches 16 channels (one chunk
+// plane) x a twelfth of the patch rows into a staging area of its own, and in the following tap it reads that back
+// four channels x four pixels at a time, transposes the 4 x 4 bytes in registers and writes each pixel's four channel
+// bytes into the patch (chunk planes with a border that is zeroed once: interior writes never touch it; rows outside the
+// image arrive as zeros from out-of-range DMA offsets).  A wave consumes only what it fetched itself, behind a counted
+// vmcnt that leaves the younger output stores in flight, so no barrier is added.
+template <int OUT, bool STREAM, bool CL, bool DIRECT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
+    static_assert(!(CL && DIRECT), "DIRECT stages an NCHW activation");
     constexpr int FM = 7, FN = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, then [2] weight stages
+    constexpr int kSlots = DIRECT ? kDirectSlots : kPlaneSlots;   // slots per chunk plane
+    constexpr int kPatch = 4 * kSlots * kChunk;                   // bytes of one patch buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, [2] weight stages, (DIRECT) [8] staging areas
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -1048,7 +1072,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     auto issue_piece = [&](const Unit& u, int cg, int buf, bool weights, int k) -> bool {
         bool any = false;
         const int q = wave + 8 * k;
-        if (q < 44) {
+        if (!DIRECT && q < 44) {
             const uint32_t first = (u.b * g.Hp + u.y0) * g.pitch;
             // channels-last: the four planes of a 64-pixel segment are read from the same cache lines, so they go out
             // together (from four waves at once): issued plane by plane, a line has left the L1 before its next use
@@ -1058,15 +1082,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 off = (first + seg * 64 + lane) * g.cin + (cg * 4 + plane) * kChunk;
             else
                 off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
-            dma16(rx, smem + buf * kPatchBytes + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
+            dma16(rx, smem + buf * kPatch + plane * (kSlots * kChunk) + seg * 1024, off);
             any = true;
         }
         if (weights && q < 36) {
-            dma16(rw, smem + 2 * kPatchBytes + (w_once ? 0 : buf) * kWStageBytes + q * 1024,
+            dma16(rw, smem + 2 * kPatch + (w_once ? 0 : buf) * kWStageBytes + q * 1024,
                   ((u.tn * g.ncg + cg) * 36 + q) * 1024 + lane * kChunk);
             any = true;
         }
         return any;
+    };
+
+    // DIRECT: piece p (0..5) of a stage.  This wave's share: chunk plane wave & 3 (16 channels), patch rows
+    // [part * part_rows, +part_rows) with part = 2p + (wave >> 2).  Per channel those rows are one run of part_rows * W
+    // bytes in memory; it is fetched as the 16-byte chunks that cover it (the run starts `delta` bytes into the first).
+    char* const staging = smem + 2 * kPatch + 2 * kWStageBytes + wave * kDirectStageBytes;
+    const int cpc = g.cpc;   // 16-byte chunks fetched per channel
+    auto direct_fetch = [&](const Unit& u, int cg, int p) {
+        const int part = 2 * p + (wave >> 2);
+        const int y_img = static_cast<int>(u.y0) - g.pad + part * g.part_rows;   // image row of the part's first row (may lie outside)
+        const int chan0 = static_cast<int>(u.b) * g.cin + cg * 64 + (wave & 3) * 16;
+#pragma unroll 1
+        for (int it = 0; it * 64 < 16 * cpc; ++it) {
+            const uint32_t e = it * 64 + lane;
+            const uint32_t ch = __umulhi(e, g.cpc_magic), k = e - ch * cpc;
+            const int start = ((chan0 + static_cast<int>(ch)) * g.H + y_img) * g.W;   // byte offset of the run (negative above image 0)
+            // a chunk outside the buffer reads zeros; whatever else it holds beside the run is never used.  Lanes past the
+            // last chunk are switched off (an out-of-range offset would still write 16 zero bytes, into the next wave's area).
+            if (e < static_cast<uint32_t>(16 * cpc))
+                dma16(rx, staging + it * 1024, static_cast<uint32_t>((start & ~15) + static_cast<int>(k) * 16));
+        }
+    };
+    auto direct_relay = [&](const Unit& u, int cg, int buf, int p) {
+        const int part = 2 * p + (wave >> 2);
+        const int row0 = part * g.part_rows;
+        const int y_img = static_cast<int>(u.y0) - g.pad + row0;
+        const int cq = lane & 3;
+        const uint32_t pq = lane >> 2;   // pixel quad inside the part (at most 16 of them)
+        const uint32_t row = __umulhi(pq, g.w4_magic), xq = pq - row * g.w4;
+        if (pq < static_cast<uint32_t>(g.part_rows * g.w4) && row0 + static_cast<int>(row) < g.rows) {
+            const int chan0 = static_cast<int>(u.b) * g.cin + cg * 64 + (wave & 3) * 16 + cq * 4;
+            const bool inside = y_img + static_cast<int>(row) >= 0 && y_img + static_cast<int>(row) < g.H;
+            uint32_t r[4] = {0u, 0u, 0u, 0u}, d[4];
+            if (inside) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int delta = (((chan0 + i) * g.H + y_img) * g.W) & 15;
+                    r[i] = *reinterpret_cast<const uint32_t*>(staging + (cq * 4 + i) * cpc * 16 + delta + pq * 4);
+                }
+            }
+            transpose4x4_bytes(r, d);
+            char* o = smem + buf * kPatch + (wave & 3) * (kSlots * kChunk) + cq * 4 +
+                      ((row0 + row) * g.pitch + g.pad + xq * 4) * kChunk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint32_t*>(o + i * kChunk) = d[i];
+        }
     };
 
     // per-channel epilogue parameters of this workgroup's channel tile, once
@@ -1228,10 +1298,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
 #endif
     int unit = blockIdx.x;
     Unit cur = decode(unit);
+    if constexpr (DIRECT) {
+        // both patch buffers start as zeros: the border columns and the slots behind the last row are never written again
+        for (int i = threadIdx.x; i < 2 * kPatch / 16; i += 512) reinterpret_cast<v4i*>(smem)[i] = v4i{0, 0, 0, 0};
+        __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < 6; ++p) {
+            direct_fetch(cur, 0, p);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            direct_relay(cur, 0, 0, p);
+        }
+    }
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) (void)issue_piece(cur, 0, 0, true, k);
     int buf = 0;
     int stores = 0;         // store instructions this wave issued after its last piece of the next stage's fetch
+    int after_patch = 0;    // DIRECT: vector memory instructions this wave issued after its last patch piece
     bool pending = false;   // `done` holds a unit that has not left yet
     Unit prev{};
     __amdgpu_buffer_rsrc_t rout = image_of(cur);
@@ -1246,7 +1328,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 uint32_t p = qfirst + i * 16;
                 if (p >= static_cast<uint32_t>(g.HoWo)) p = g.HoWo - 1;   // rows past the image: computed, never stored
                 const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
-                aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + ((y - cur.y0) * g.pitch + x) * kChunk;
+                aoff[i] = (lane >> 4) * (kSlots * kChunk) + ((y - cur.y0) * g.pitch + x) * kChunk;
             }
         }
         for (int cg = 0; cg < g.ncg; ++cg) {
@@ -1269,8 +1351,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
             const Unit nxt = decode(fetch ? nunit : unit);
             MIQ_PLANAR_STAMP(3)
             const bool flush = pending && cg == 0;
-            const char* patch = smem + buf * kPatchBytes;
-            const char* wst = smem + 2 * kPatchBytes + (w_once ? 0 : buf) * kWStageBytes + w_lane;
+            const char* patch = smem + buf * kPatch;
+            const char* wst = smem + 2 * kPatch + (w_once ? 0 : buf) * kWStageBytes + w_lane;
             {
                 v4i af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
                 auto read_tap = [&](auto S, int kh, int kw) {
@@ -1284,8 +1366,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 };
                 auto tap = [&](auto T) {
                     constexpr int t = decltype(T)::value, s = t & 1;
+                    if constexpr (DIRECT && t >= 1 && t <= 6) {
+                        if (fetch) {   // piece t - 1 has landed once only what was issued after it is left in flight
+                            wait_vmcnt_upto16(after_patch);
+                            direct_relay(nxt, ncg, buf ^ 1, t - 1);
+                        }
+                    }
+                    if constexpr (DIRECT && t < 6) {
+                        if (fetch) {
+                            direct_fetch(nxt, ncg, t);
+                            stores = 0;
+                            after_patch = 0;
+                        }
+                    }
                     if constexpr (t < 6) {
-                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_once, t)) stores = 0;
+                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_once, t)) {
+                            stores = 0;
+                            if constexpr (DIRECT) after_patch += 1;
+                        }
                     }
                     if constexpr (t + 1 < 9) read_tap(std::integral_constant<int, (t + 1) & 1>{}, (t + 1) / 3, (t + 1) % 3);
 #pragma unroll
@@ -1299,7 +1397,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                     // keeps so much in flight that it spills; left alone, it converts the whole unit ahead of the first tap).  The two waves of a SIMD run half a tap
                     // apart (priorities below), so one's conversion is covered by the other's MFMAs.
                     __builtin_amdgcn_sched_barrier(0);
-                    if (flush) stores += store_step(rout, prev, T);
+                    if (flush) {
+                        const int n = store_step(rout, prev, T);
+                        stores += n;
+                        if constexpr (DIRECT) after_patch += n;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 read_tap(std::integral_constant<int, 0>{}, 0, 0);
@@ -1344,13 +1446,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     }
 }
 
-template <int OUT, bool CL = false>
+template <int OUT, bool CL = false, bool DIRECT = false>
 int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
-    void (*kern)(PlanarArgs) = conv3x3_patch_kernel<OUT, false, CL>;
+    void (*kern)(PlanarArgs) = conv3x3_patch_kernel<OUT, false, CL, DIRECT>;
     if constexpr (!CL) {
-        if (stream_out) kern = conv3x3_patch_kernel<OUT, true, false>;
+        if (stream_out) kern = conv3x3_patch_kernel<OUT, true, false, DIRECT>;
     }
-    constexpr int kLds = 2 * kPlanarStage;   // all of a CU's LDS
+    // all of a CU's LDS (DIRECT: smaller patch planes make room for the eight staging areas)
+    constexpr int kLds = DIRECT ? 2 * 4 * kDirectSlots * kChunk + 2 * kWStageBytes + 8 * kDirectStageBytes : 2 * kPlanarStage;
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     // one persistent workgroup per CU, each keeping one channel tile
     int grid = g.units < 256 ? g.units : 256 - 256 % g.tiles_n;
@@ -1707,6 +1811,50 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
 
     int8_t* xp = static_cast<int8_t*>(workspace);
     int8_t* wp = xp + miq::round_up(G.xp_bytes, 256);
+
+    // 3 x 3 / stride 1 layers whose rows are whole dwords: the patch kernel stages the NCHW activation itself (no padded
+    // copy, no re-layout launch); only the filters are re-laid, into the workspace.
+    if (G.planar && W % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
+        !(dev_switch("MIQ_CONV_DIRECT") && dev_switch("MIQ_CONV_DIRECT")[0] == '0')) {
+        const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
+        int64_t rows = 0;
+        for (int64_t p0 = 0; p0 < HoWo; p0 += kTM)
+            rows = std::max(rows, (std::min<int64_t>(p0 + kTM, HoWo) - 1) / G.Wo - p0 / G.Wo + 3);
+        const int64_t part_rows = miq::ceil_div(rows, 12);
+        const int64_t cpc = miq::ceil_div(part_rows * W + 12, 16);
+        if (rows * G.Wp + 2 <= kDirectSlots && 16 * cpc * 16 <= kDirectStageBytes && part_rows * (W / 4) <= 16 && HoWo < 65536 &&
+            Cin == 64) {   // (one input-channel group: with more, the staging work costs what the re-layout launch did)
+            const uint32_t wtotal = static_cast<uint32_t>(G.wp_bytes / 4);
+            const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
+            pack_conv_weight_planar_kernel<<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
+            if (int rc = miq::check_launch("pack_conv_weight_planar_kernel")) return rc;
+            PlanarArgs pa{};
+            pa.wp = wp; pa.bias = bias; pa.alpha = alpha; pa.out = out; pa.beta = beta;
+            pa.Cout = (int)Cout; pa.ncg = (int)(Cin / 64); pa.tiles_n = (int)miq::ceil_div(Cout, 64);
+            pa.tiles_img = (int)tiles_img;
+            pa.pitch = (int)G.Wp; pa.Hp = (int)G.Hp; pa.Wo = (int)G.Wo; pa.HoWo = (int)HoWo;
+            pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
+            pa.wp_bytes = (uint32_t)G.wp_bytes;
+            pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
+            pa.x = x; pa.xp = x; pa.x_bytes = pa.xp_bytes = (uint32_t)(B * Cin * H * W);
+            pa.cin = (int)Cin; pa.H = (int)H; pa.W = (int)W; pa.pad = (int)pad;
+            pa.rows = (int)rows; pa.part_rows = (int)part_rows; pa.w4 = (int)(W / 4);
+            pa.w4_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(pa.w4)) + 1u;
+            pa.cpc = (int)cpc;
+            pa.cpc_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(cpc)) + 1u;
+            if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))
+                pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
+            const int64_t units = B * pa.tiles_img * pa.tiles_n;
+            MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
+            pa.units = (int)units;
+            const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
+            switch (out_dtype) {
+                case MIQ_F32: return launch_planar<kOutF32, false, true>(pa, stream_out, st);
+                case MIQ_BF16: return launch_planar<kOutBF16, false, true>(pa, stream_out, st);
+                default: return launch_planar<kOutI32, false, true>(pa, stream_out, st);
+            }
+        }
+    }
     {
         const int cblocks = static_cast<int>(miq::ceil_div(G.Cp, 64));
         bool packed = false;   // the weight re-layout rode along with the activation re-layout

@@ -273,6 +273,9 @@ CONV_SHAPES = [
     # from aligned 8-byte runs; odd sizes, ragged channels, stride 3 and a 3-channel image by single bytes)
     (2, 64, 16, 16, 128, 1, 2, 0), (3, 70, 24, 40, 20, 1, 2, 0), (2, 16, 15, 17, 8, 1, 2, 0),
     (2, 32, 13, 13, 8, 1, 3, 0), (1, 3, 9, 9, 4, 1, 2, 0), (2, 8, 12, 20, 8, 1, 2, 0), (2, 128, 56, 56, 64, 1, 2, 0),
+    # the patch kernel: staging the NCHW activation itself (3 x 3 / 1, 64 input channels, W % 4 == 0; one and three channel
+    # tiles, a ragged last tile) and from the padded copy (two channel groups; a patch that only fits that form)
+    (3, 64, 56, 56, 64, 3, 1, 1), (4, 128, 28, 28, 128, 3, 1, 1), (5, 64, 30, 28, 192, 3, 1, 1), (4, 64, 40, 40, 64, 3, 1, 0),
     # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
     (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
 ]
