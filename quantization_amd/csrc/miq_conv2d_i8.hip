@@ -36,6 +36,7 @@ struct ConvGeom {
     bool planar;
     int64_t pitch;   // pixels per padded row (Wp rounded up to 4)
     int64_t ptot;    // flat padded pixels B * Hp * pitch
+    int64_t group;   // small images: whole images per tile of the patch kernel (1 = tiles of one image)
     // 1 x 1 filters with a stride and no padding read only every stride-th pixel of every stride-th row: the
     // re-layout keeps just those (sub = the caller's stride, Hs x Ws = the caller's image) and the problem
     // continues as a stride-1 convolution over an Ho x Wo image (H, W, stride above are then the reduced ones).
@@ -50,9 +51,42 @@ constexpr int kPatchBytes = 4 * kPlaneSlots * kChunk;   // 44 KiB
 constexpr int kWStageBytes = 9 * 4 * 64 * kChunk;       // 36 KiB: [tap][chunk][channel][16 B]
 constexpr int kPlanarStage = kPatchBytes + kWStageBytes;
 
+// How the patch kernel tiles an image of HoWo output pixels whose padded copy has Hp rows of `pitch` slots: tiles of kTM
+// consecutive pixels of one image (group = 1) if the padded rows a tile touches (+2) fit `slots` and the tiles are mostly
+// pixels, or, for images of at most half a tile, `group` whole images per tile (their padded copies are one run in memory).
+// False if neither fits.
+bool patch_tiling(int64_t HoWo, int64_t Wo, int64_t Hp, int64_t pitch, int64_t slots, int64_t& group) {
+    group = 1;
+    if (2 * HoWo <= kTM) {
+        group = std::min<int64_t>(kTM / HoWo, (slots - 2) / (Hp * pitch));
+        const bool ok = group >= 2 && 5 * group * HoWo >= 4 * kTM;   // ... and still mostly pixels
+        if (!ok) group = 1;
+        return ok;
+    }
+    int64_t rows = 0;
+    for (int64_t p0 = 0; p0 < HoWo; p0 += kTM) {
+        const int64_t p1 = std::min<int64_t>(p0 + kTM, HoWo) - 1;
+        rows = std::max(rows, p1 / Wo - p0 / Wo + 3);
+    }
+    const int64_t tiles_img = ceil_div(HoWo, kTM);
+    return rows * pitch + 2 <= slots && 5 * HoWo >= 4 * tiles_img * kTM;
+}
+
+// The fields of PlanarArgs that describe the units, from the tiling above.
+template <typename Args>
+void set_patch_units(Args& pa, int64_t B, int64_t HoWo, int64_t Hp, int64_t pitch, int64_t group) {
+    pa.group = (int)group;
+    pa.B = (int)B;
+    pa.img_slots = (int)(Hp * pitch);
+    pa.pix_end = (int)(group * HoWo);
+    pa.hw_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(HoWo)) + 1u;
+    pa.tiles_img = group > 1 ? 1 : (int)ceil_div(HoWo, kTM);
+    pa.units = (int)(ceil_div(B, group) * pa.tiles_img * pa.tiles_n);
+}
+
 bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                int64_t pad, ConvGeom& g, bool relayout = true) {   // relayout = false: the caller's channels-last form is staged as it is
-    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 1, H, W};
+    g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 1, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
     const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
     if (relayout && KH == 1 && KW == 1 && pad == 0 && stride > 1 && H * W < (1ll << 30) && !(ss && ss[0] == '0')) {
@@ -81,14 +115,7 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     g.planar = false;
     if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
         !(sw && sw[0] == '0')) {
-        int64_t rows = 0;
-        for (int64_t p0 = 0; p0 < g.Ho * g.Wo; p0 += kTM) {
-            const int64_t p1 = std::min<int64_t>(p0 + kTM, g.Ho * g.Wo) - 1;
-            rows = std::max(rows, p1 / g.Wo - p0 / g.Wo + 3);
-        }
-        // ... and tiles that are mostly pixels: an image smaller than a tile would leave its fragments empty
-        const int64_t tiles_img = ceil_div(g.Ho * g.Wo, kTM);
-        g.planar = rows * g.pitch + 2 <= kPlaneSlots && 5 * g.Ho * g.Wo >= 4 * tiles_img * kTM;
+        g.planar = patch_tiling(g.Ho * g.Wo, g.Wo, g.Hp, g.pitch, kPlaneSlots, g.group);
     }
     if (g.planar) {
         g.xp_bytes = g.ptot * Cin;
@@ -980,6 +1007,11 @@ struct PlanarArgs {
     int cin;
     int o_img, o_row, o_pix, o_off;
     unsigned long long* stamps;   // developer library only: [workgroup][stage 0..7][8] shader-clock stamps, or null
+    // small images: a unit is `group` consecutive whole images (tiles_img == 1); 1 = a unit is a tile of one image
+    int group, B;
+    int img_slots;                // Hp * pitch: patch slots of one image
+    int pix_end;                  // group * HoWo: pixels of a unit that exist
+    uint32_t hw_magic;            // floor(2^32 / HoWo) + 1
     // NCHW activation staged directly (DIRECT kernels): x[B][cin][H][W], W % 4 == 0
     const int8_t* x;
     uint32_t x_bytes;
@@ -1017,7 +1049,7 @@ __device__ __forceinline__ void wait_vmcnt_upto16(int n) {
 }
 
 // One persistent workgroup per CU (eight waves, 256 registers each, all of the CU's LDS) walks (image, tile, channel
-// tile) units, with the phases of a stage overlapped in software:
+// tile) units (small images: a unit is `group` consecutive whole images, whose padded copies are one run in memory), with the phases of a stage overlapped in software:
 //   * LDS holds two stages (patch + weights): the fetch of stage s + 1 is issued piece by piece among the filter taps
 //     of stage s and lands under its MFMAs;
 //   * the fragments of filter tap t + 1 are read from LDS while the MFMAs of tap t run;
@@ -1062,8 +1094,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
         Unit u;
         u.tn = static_cast<uint32_t>(unit % g.tiles_n);
         const uint32_t t = static_cast<uint32_t>(unit / g.tiles_n);
-        u.b = t / g.tiles_img;
-        u.p0 = (t - u.b * g.tiles_img) * kTM;
+        const uint32_t bi = t / g.tiles_img;
+        u.b = bi * g.group;   // the unit's (first) image
+        u.p0 = (t - bi * g.tiles_img) * kTM;
         u.y0 = u.p0 / g.Wo;
         return u;
     };
@@ -1183,8 +1216,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
         // (opaque: the conversion below then stays at this point of the instruction stream, among the MFMAs of the tap
         // it was written beside, instead of being computed for the whole unit ahead of the first tap)
         asm volatile("" : "+v"(a0), "+v"(a1));
-        const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
-        const uint32_t off = p < static_cast<uint32_t>(g.HoWo) ? (y * g.o_row + x * g.o_pix + g.o_off + n0) * kEsz : kOob;
+        const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;   // image of the unit, pixel inside it
+        const uint32_t y = __umulhi(pp, g.wo_magic), x = pp - y * g.Wo;
+        const uint32_t off = p < static_cast<uint32_t>(g.pix_end) ? (im * g.o_img + y * g.o_row + x * g.o_pix + g.o_off + n0) * kEsz : kOob;
         if constexpr (OUT == kOutI32) {
             put16(r, off, a0);
             put16(r, off + 16, a1);
@@ -1218,12 +1252,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     auto store_row_nchw = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
         constexpr int i = decltype(I)::value;
         const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4;   // HoWo % 4 == 0: four pixels in or out together
+        const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;   // image of the unit, pixel inside it
+        const uint32_t at = im * g.Cout * g.HoWo + pp;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
             v4i a = done[i][j];
             asm volatile("" : "+v"(a));   // (opaque, as above)
-            const uint32_t off = p < static_cast<uint32_t>(g.HoWo) && n < g.Cout ? (n * g.HoWo + p) * kEsz : kOob;
+            const uint32_t off = p < static_cast<uint32_t>(g.pix_end) && n < g.Cout ? (n * g.HoWo + at) * kEsz : kOob;
             if constexpr (OUT == kOutI32) {
                 put16(r, off, a);
             } else {
@@ -1242,6 +1278,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     auto store_pair_nchw_bf16 = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
         constexpr int i = decltype(I)::value;   // the second row of the pair
         const uint32_t p = u.p0 + wm * FM * 16 + (i - 1) * 16 + paired_offset(lane);   // HoWo % 8 == 0
+        const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;
+        const uint32_t at = im * g.Cout * g.HoWo + pp;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
@@ -1255,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 h[e] = pack4_bf16(lo[0], lo[1], hi[0], hi[1]);
             }
             const v4i v = pair_rows_bf16(h[0], h[1]);
-            put16(r, p < static_cast<uint32_t>(g.HoWo) && n < g.Cout ? (n * g.HoWo + p) * kEsz : kOob, v);
+            put16(r, p < static_cast<uint32_t>(g.pix_end) && n < g.Cout ? (n * g.HoWo + at) * kEsz : kOob, v);
         }
         return FN;
     };
@@ -1282,8 +1320,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     };
     // the finished unit's image as a buffer (offsets inside one image fit 31 bits: checked by the host)
     const uint32_t img_bytes = CL ? static_cast<uint32_t>(g.o_img) * kEsz : static_cast<uint32_t>(g.Cout) * g.HoWo * kEsz;
-    auto image_of = [&](const Unit& u) {
-        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, img_bytes);
+    auto image_of = [&](const Unit& u) {   // (the unit's images that exist: stores to one past the batch are dropped)
+        const uint32_t n = static_cast<uint32_t>(g.B) - u.b < static_cast<uint32_t>(g.group) ? g.B - u.b : g.group;
+        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, n * img_bytes);
     };
 
     const int w_lane = CL ? ((lane >> 4) * 64 + wn * 32 + ((lane & 15) >> 2) * 8 + (lane & 3)) * kChunk
@@ -1326,9 +1365,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 uint32_t p = qfirst + i * 16;
-                if (p >= static_cast<uint32_t>(g.HoWo)) p = g.HoWo - 1;   // rows past the image: computed, never stored
-                const uint32_t y = __umulhi(p, g.wo_magic), x = p - y * g.Wo;
-                aoff[i] = (lane >> 4) * (kSlots * kChunk) + ((y - cur.y0) * g.pitch + x) * kChunk;
+                if (p >= static_cast<uint32_t>(g.pix_end)) p = g.pix_end - 1;   // rows past the unit: computed, never stored
+                const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;
+                const uint32_t y = __umulhi(pp, g.wo_magic), x = pp - y * g.Wo;
+                aoff[i] = (lane >> 4) * (kSlots * kChunk) + (im * g.img_slots + (y - cur.y0) * g.pitch + x) * kChunk;
             }
         }
         for (int cg = 0; cg < g.ncg; ++cg) {
@@ -1814,7 +1854,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
 
     // 3 x 3 / stride 1 layers whose rows are whole dwords: the patch kernel stages the NCHW activation itself (no padded
     // copy, no re-layout launch); only the filters are re-laid, into the workspace.
-    if (G.planar && W % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
+    if (G.planar && G.group == 1 && W % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
         !(dev_switch("MIQ_CONV_DIRECT") && dev_switch("MIQ_CONV_DIRECT")[0] == '0')) {
         const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
         int64_t rows = 0;
@@ -1844,9 +1884,8 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.cpc_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(cpc)) + 1u;
             if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))
                 pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
-            const int64_t units = B * pa.tiles_img * pa.tiles_n;
-            MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
-            pa.units = (int)units;
+            MIQ_REQUIRE(B * tiles_img * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
+            set_patch_units(pa, B, HoWo, G.Hp, G.Wp, 1);
             const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
             switch (out_dtype) {
                 case MIQ_F32: return launch_planar<kOutF32, false, true>(pa, stream_out, st);
@@ -1930,9 +1969,8 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
         if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
             pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
-        const int64_t units = B * pa.tiles_img * pa.tiles_n;
-        MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
-        pa.units = (int)units;
+        MIQ_REQUIRE(B * miq::ceil_div(G.Ho * G.Wo, kTM) * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
+        set_patch_units(pa, B, G.Ho * G.Wo, G.Hp, G.pitch, G.group);
         // as below: outputs far beyond the Infinity Cache stream past it (16-byte stores only)
         const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
         switch (out_dtype) {
@@ -2064,15 +2102,12 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
     const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
     if (pw.planar_at && stride == 1 && G.M >= 4 * kTM && miq::aligned(out, 16) && miq::aligned(alpha, 16) &&
         miq::aligned(bias, 16) && !(dev_switch("MIQ_CONV_PLANAR") && dev_switch("MIQ_CONV_PLANAR")[0] == '0')) {
-        const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
-        int64_t rows = 0;
-        for (int64_t p0 = 0; p0 < HoWo; p0 += kTM)
-            rows = std::max(rows, (std::min<int64_t>(p0 + kTM, HoWo) - 1) / G.Wo - p0 / G.Wo + 3);
-        if (rows * G.Wp + 2 <= kPlaneSlots && 5 * HoWo >= 4 * tiles_img * kTM && HoWo < 65536) {
+        const int64_t HoWo = G.Ho * G.Wo;
+        int64_t group = 1;
+        if (patch_tiling(HoWo, G.Wo, G.Hp, G.Wp, kPlaneSlots, group) && HoWo < 65536) {
             PlanarArgs pa{};
             pa.xp = x; pa.wp = wp + pw.planar_at; pa.bias = bias; pa.alpha = alpha; pa.out = out; pa.beta = beta;
             pa.Cout = (int)Cout; pa.ncg = (int)(Cin / 64); pa.tiles_n = (int)(Cout / 64);
-            pa.tiles_img = (int)tiles_img;
             pa.pitch = (int)G.Wp; pa.Hp = (int)G.Hp; pa.Wo = (int)G.Wo; pa.HoWo = (int)HoWo;
             pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
             pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)pw.planar_bytes;
@@ -2081,9 +2116,8 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
             pa.o_off = (int)((out_pad * Wop + out_pad) * Cout);
             if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
                 pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
-            const int64_t units = B * pa.tiles_img * pa.tiles_n;
-            MIQ_REQUIRE(units < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_nhwc: too many tiles");
-            pa.units = (int)units;
+            MIQ_REQUIRE(B * miq::ceil_div(HoWo, kTM) * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_nhwc: too many tiles");
+            set_patch_units(pa, B, HoWo, G.Hp, G.Wp, group);
             switch (out_dtype) {
                 case MIQ_F32: return launch_planar<kOutF32, true>(pa, false, st);
                 case MIQ_BF16: return launch_planar<kOutBF16, true>(pa, false, st);

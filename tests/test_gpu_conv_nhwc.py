@@ -38,6 +38,8 @@ SHAPES = [  # B, Cin, H, W, Cout, k, stride, pad
     (256, 64, 28, 28, 64, 3, 1, 1),    # the LDS-resident-patch kernel, two tiles per image
     (3, 64, 56, 56, 64, 3, 1, 1), (4, 128, 28, 28, 128, 3, 1, 1),      # the same: one / two channel groups and channel tiles
     (5, 64, 30, 26, 192, 3, 1, 1), (4, 64, 40, 40, 64, 3, 1, 0),        # ... a ragged last tile, no padding
+    # the patch kernel with several small images per tile: two 14 x 14 images (odd batch), eight 7 x 7 images (ragged batch)
+    (11, 64, 14, 14, 64, 3, 1, 1), (43, 128, 7, 7, 128, 3, 1, 1),
     # the stem kernel (4-byte pixels, 5-8 filter columns, stride 2): ragged tiles, two channel tiles, 8 x 8 filters
     (2, 4, 32, 32, 64, 7, 2, 3), (3, 4, 45, 40, 80, 7, 2, 3), (2, 4, 33, 45, 32, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
 ]

@@ -276,6 +276,8 @@ CONV_SHAPES = [
     # the patch kernel: staging the NCHW activation itself (3 x 3 / 1, 64 input channels, W % 4 == 0; one and three channel
     # tiles, a ragged last tile) and from the padded copy (two channel groups; a patch that only fits that form)
     (3, 64, 56, 56, 64, 3, 1, 1), (4, 128, 28, 28, 128, 3, 1, 1), (5, 64, 30, 28, 192, 3, 1, 1), (4, 64, 40, 40, 64, 3, 1, 0),
+    # the patch kernel with several small images per tile (a last tile with one image; two channel groups and tiles)
+    (11, 64, 14, 14, 64, 3, 1, 1), (12, 128, 14, 14, 192, 3, 1, 1),
     # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
     (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
 ]
