@@ -194,6 +194,30 @@ def llama8b_mlp_decode(N_, dev):
     return res
 
 
+def gemm_other_shapes(N_, dev):
+    """The int8 GEMM beside the headline case: BASELINE config 2 (M = N = K = 4096) with fp32 and bf16 output, and the
+    headline shape with bf16 output; kernel time by HIP events per launch after a clock ramp, each against the int8 peak."""
+    res = {}
+    for S, dt in ((4096, torch.float32), (4096, torch.bfloat16), (8192, torch.bfloat16)):
+        x = torch.randint(-128, 128, (S, S), dtype=torch.int32, device=dev).to(torch.int8)
+        w = torch.randint(-128, 128, (S, S), dtype=torch.int32, device=dev).to(torch.int8)
+        alpha = torch.rand(S, device=dev) * 1e-3
+        bias = torch.randn(S, device=dev)
+        out = torch.empty(S, S, dtype=dt, device=dev)
+
+        def step():
+            N_.gemm_i8(x, w, bias=bias, alpha=alpha, out_dtype=dt, out=out)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.15:   # clock ramp
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+        ms = median_ms(step, 50, 10)
+        res[f"{S}x{S}x{S}_{str(dt).split('.')[-1]}_out"] = {"kernel_ms": round(ms, 4), "roofline": mfma_roofline(2.0 * S * S * S, ms)}
+        del x, w, out
+    return res
+
+
 RESNET18_CONVS = [  # (Cin, H, Cout, k, stride, pad, occurrences in ResNet-18)
     (3, 224, 64, 7, 2, 3, 1), (64, 56, 64, 3, 1, 1, 4), (64, 56, 128, 3, 2, 1, 1), (128, 28, 128, 3, 1, 1, 3),
     (64, 56, 128, 1, 2, 0, 1), (128, 28, 256, 3, 2, 1, 1), (256, 14, 256, 3, 1, 1, 3), (128, 28, 256, 1, 2, 0, 1),
@@ -570,6 +594,7 @@ def main():
         }
         line["extra"].update(extras)
         if world == 1 and not args.no_extras:
+            line["extra"]["gemm_other_shapes"] = gemm_other_shapes(N_, dev)
             line["extra"]["llama3_8b_mlp_decode"] = llama8b_mlp_decode(N_, dev)
             line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
             line["extra"]["conv_int8"] = conv_int8(N_, dev)
