@@ -223,9 +223,15 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
                         if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[so[k]])) << (8 * k);
                 } else {
                     const int8_t* src = x + (b * Cin + c) * HW + pf;
+                    if (pf + 3 < HW) {   // four pixels inside the plane: one dword load of any alignment
+                        uint32_t v;
+                        __builtin_memcpy(&v, src, 4);
+                        r[j] = v;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                        for (int k = 0; k < 4; ++k)
+                            if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                    }
                 }
             }
         }
@@ -400,6 +406,10 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
     else
         pack_conv_weight_items(a.w, a.wp, a.weight_total, a.Cin, a.KH, a.KW, a.Cp, a.L, a.Lp, first, step);
 }
+
+// four dwords that are only dword-aligned in memory (a global store of 16 bytes needs no more)
+typedef int v4i_dw __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v4f_dw __attribute__((ext_vector_type(4), aligned(4)));
 
 struct ConvArgs {
     const int8_t* xp;
@@ -658,6 +668,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
                                    dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
                 }
             } else {
+                // Images whose pixel count is not a multiple of 4 (7 x 7): the four pixels are still consecutive in memory
+                // when they share an image, only not 16-byte aligned: one vector store of dword alignment (global
+                // stores need no more) instead of four scalars.
+                const int b0 = m / g.HoWo, p0 = m - b0 * g.HoWo;
+                if (OUT != kOutBF16 && m + 3 < g.M && p0 + 3 < g.HoWo) {
+                    const size_t idx = (static_cast<size_t>(b0) * g.Cout + n) * g.HoWo + p0;
+                    if constexpr (OUT == kOutI32) {
+                        *reinterpret_cast<v4i_dw*>(static_cast<int*>(g.out) + idx) = a;
+                    } else if constexpr (OUT == kOutF32) {
+                        *reinterpret_cast<v4f_dw*>(static_cast<float*>(g.out) + idx) =
+                            v4f{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta), dequant1(a[2], bi, al, g.beta),
+                                dequant1(a[3], bi, al, g.beta)};
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int me = m + e;
@@ -950,6 +975,19 @@ __global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
                                            dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta));
                         }
                     } else {
+                        // (as in conv_i8_kernel: a dword-aligned vector store where the four pixels share an image)
+                        const int b0 = m / g.HoWo, p0 = m - b0 * g.HoWo;
+                        if (OUT != kOutBF16 && m + 3 < g.M && p0 + 3 < g.HoWo) {
+                            const size_t idx = (static_cast<size_t>(b0) * g.Cout + n) * g.HoWo + p0;
+                            if constexpr (OUT == kOutI32) {
+                                *reinterpret_cast<v4i_dw*>(static_cast<int*>(g.out) + idx) = a;
+                            } else if constexpr (OUT == kOutF32) {
+                                *reinterpret_cast<v4f_dw*>(static_cast<float*>(g.out) + idx) =
+                                    v4f{dequant1(a[0], bi, al, g.beta), dequant1(a[1], bi, al, g.beta),
+                                        dequant1(a[2], bi, al, g.beta), dequant1(a[3], bi, al, g.beta)};
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int me = m + e;
