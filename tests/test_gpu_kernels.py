@@ -292,6 +292,22 @@ def test_conv_i32_bit_exact(N, B, C, H, W, Co, k, s, p):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("B,C,H,W,Co,pad,shift", [(3, 64, 56, 56, 64, 1, 4), (8, 64, 30, 28, 64, 0, 4), (8, 64, 30, 28, 70, 1, 12),
+                                                  (3, 64, 56, 56, 64, 1, 1)])
+def test_conv_3x3_on_an_activation_that_is_not_16_byte_aligned(N, B, C, H, W, Co, pad, shift):
+    """3 x 3 / stride 1 layers with 64 input channels stage the NCHW activation themselves in 16-byte chunks when its base
+    is at least dword-aligned (shift 4, 12: the chunks then start inside a channel's first row), and go through the padded
+    copy otherwise (shift 1); with and without padding."""
+    flat = torch.zeros(B * C * H * W + 64, dtype=torch.int8, device="cuda")
+    x = flat[shift:shift + B * C * H * W].view(B, C, H, W)
+    x.copy_(rand_i8((B, C, H, W), B + H + shift).cuda())
+    assert x.data_ptr() % 16 == shift % 16
+    w = rand_i8((Co, C, 3, 3), Co + shift).cuda()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=1, padding=pad).to(torch.int32)
+    out = N.conv2d_i8(x, w, 1, pad, out_dtype=torch.int32)
+    assert torch.equal(out, ref)
+
+
 def test_conv_3x3_random_shapes_vs_torch(N):
     """Seeded random 3 x 3 / stride 1 layers with whole 64-channel groups (most take the LDS-resident-patch
     kernel, the small ones the im2col-order kernel) against F.conv2d in float64, exact on these integers."""
