@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     // bytes in memory; it is fetched as the 16-byte chunks that cover it (the run starts `delta` bytes into the first).
     char* const staging = smem + 2 * kPatch + 2 * kWStageBytes + wave * kDirectStageBytes;
     const int cpc = g.cpc;   // 16-byte chunks fetched per channel
-    auto direct_fetch = [&](const Unit& u, int cg, int p) {
+    auto direct_fetch = [&](const Unit& u, int cg, int p, char* staging) {
         const int part = 2 * p + (wave >> 2);
         const int y_img = static_cast<int>(u.y0) - g.pad + part * g.part_rows;   // image row of the part's first row (may lie outside)
         const int chan0 = static_cast<int>(u.b) * g.cin + cg * 64 + (wave & 3) * 16;
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 dma16(rx, staging + it * 1024, static_cast<uint32_t>((start & ~15) + static_cast<int>(k) * 16));
         }
     };
-    auto direct_relay = [&](const Unit& u, int cg, int buf, int p) {
+    auto direct_relay = [&](const Unit& u, int cg, int buf, int p, const char* staging) {
         const int part = 2 * p + (wave >> 2);
         const int row0 = part * g.part_rows;
         const int y_img = static_cast<int>(u.y0) - g.pad + row0;
@@ -1375,19 +1375,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
 #endif
     int unit = blockIdx.x;
     Unit cur = decode(unit);
+    // DIRECT, before the loop: where piece p of this wave lands.  The LDS that is idle until the loop starts (the second
+    // patch buffer, the second weight stage and the staging areas) holds 49 wave-pieces: the first stage's six pieces are
+    // fetched at once and re-laid together.
+    auto idle_of = [&](int p) -> char* {
+        const int j = p * 8 + wave;
+        return j < 21 ? smem + kPatch + j * kDirectStageBytes : smem + 2 * kPatch + kWStageBytes + (j - 21) * kDirectStageBytes;
+    };
     if constexpr (DIRECT) {
+        static_assert(21 * kDirectStageBytes <= kPatch && 27 * kDirectStageBytes <= kWStageBytes + 8 * kDirectStageBytes, "idle LDS");
         // both patch buffers start as zeros: the border columns and the slots behind the last row are never written again
-        for (int i = threadIdx.x; i < 2 * kPatch / 16; i += 512) reinterpret_cast<v4i*>(smem)[i] = v4i{0, 0, 0, 0};
+        for (int i = threadIdx.x; i < kPatch / 16; i += 512) reinterpret_cast<v4i*>(smem)[i] = v4i{0, 0, 0, 0};
         __syncthreads();
 #pragma unroll 1
-        for (int p = 0; p < 6; ++p) {
-            direct_fetch(cur, 0, p);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            direct_relay(cur, 0, 0, p);
-        }
+        for (int p = 0; p < 6; ++p) direct_fetch(cur, 0, p, idle_of(p));
     }
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) (void)issue_piece(cur, 0, 0, true, k);
+    if constexpr (DIRECT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int p = 0; p < 6; ++p) direct_relay(cur, 0, 0, p, idle_of(p));
+        __syncthreads();   // every wave has read its pieces: the second patch buffer can be cleared
+        for (int i = threadIdx.x; i < kPatch / 16; i += 512) reinterpret_cast<v4i*>(smem + kPatch)[i] = v4i{0, 0, 0, 0};
+    }
     int buf = 0;
     int stores = 0;         // store instructions this wave issued after its last piece of the next stage's fetch
     int after_patch = 0;    // DIRECT: vector memory instructions this wave issued after its last patch piece
@@ -1447,12 +1458,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                     if constexpr (DIRECT && t >= 1 && t <= 6) {
                         if (fetch) {   // piece t - 1 has landed once only what was issued after it is left in flight
                             wait_vmcnt_upto16(after_patch);
-                            direct_relay(nxt, ncg, buf ^ 1, t - 1);
+                            direct_relay(nxt, ncg, buf ^ 1, t - 1, staging);
                         }
                     }
                     if constexpr (DIRECT && t < 6) {
                         if (fetch) {
-                            direct_fetch(nxt, ncg, t);
+                            direct_fetch(nxt, ncg, t, staging);
                             stores = 0;
                             after_patch = 0;
                         }
