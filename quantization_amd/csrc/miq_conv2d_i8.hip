@@ -1915,7 +1915,8 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             Cin == 64) {   // (one input-channel group: with more, the staging work costs what the re-layout launch did)
             const uint32_t wtotal = static_cast<uint32_t>(G.wp_bytes / 4);
             const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
-            pack_conv_weight_planar_kernel<<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
+            if (!dev_switch("MIQ_CONV_SKIP_WPACK"))   // timing-only: the workspace still holds the last call's filters
+                pack_conv_weight_planar_kernel<<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
             if (int rc = miq::check_launch("pack_conv_weight_planar_kernel")) return rc;
             PlanarArgs pa{};
             pa.wp = wp; pa.bias = bias; pa.alpha = alpha; pa.out = out; pa.beta = beta;
@@ -1957,7 +1958,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.Cout = (int)Cout;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.pitch + 2 * pad * H));
-            pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+            pa.weight_total = dev_switch("MIQ_CONV_SKIP_WPACK") ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
@@ -1978,7 +1979,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.KH = (int)KH; pa.KW = (int)KW; pa.L = (int)G.L; pa.Lp = (int)G.Lp;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
-            pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+            pa.weight_total = dev_switch("MIQ_CONV_SKIP_WPACK") ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             pa.sub = (int)G.sub; pa.Ws = (int)G.Ws; pa.HWs = (int)(G.Hs * G.Ws);
             // about four border pixels / weight dwords per extra thread, spread over the images' grid rows
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);

@@ -3,7 +3,7 @@
 s_memtime between the segments of every phase and prints cycles per K-tile for each
 (phase, segment), median over waves, for the two wave groups.
 
-    python tools/gemm_stamps.py [size]
+    python tools/gemm_stamps.py [size] [s|t]      (t: the two-segment schedule)
 """
 import os
 import sys
@@ -23,7 +23,8 @@ alpha = torch.rand(size, generator=g, device="cuda") * 1e-3
 out = torch.empty(size, size, dtype=torch.float32, device="cuda")
 tiles = ((size + 255) // 256) ** 2
 stamps = torch.zeros(tiles * 8 * 20, dtype=torch.int32, device="cuda")
-os.environ["MIQ_GEMM_ABL"] = "s"
+which = sys.argv[2] if len(sys.argv) > 2 else "s"
+os.environ["MIQ_GEMM_ABL"] = which
 os.environ["MIQ_GEMM_STAMPS"] = f"{stamps.data_ptr():x}"
 for _ in range(20):
     N.gemm_i8(a, w, alpha=alpha, out=out)
@@ -40,6 +41,6 @@ names = ["issue reads+DMA", "wait DMA", "barrier 1", "MFMA issue", "barrier 2"]
 for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     med = s[:, sl].reshape(-1, 4, 5).median(dim=0).values
     print(grp)
-    for p in range(4):
+    for p in range(4 if which == "s" else 2):
         print(f"  phase {p + 1}: " + "  ".join(f"{names[i]} {med[p, i]:6.0f}" for i in range(5)) + f"   total {med[p].sum():6.0f}")
     print(f"  K-tile total {med.sum():.0f} cycles; by segment: " + "  ".join(f"{names[i]} {med[:, i].sum():.0f}" for i in range(5)))
