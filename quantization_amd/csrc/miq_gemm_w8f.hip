@@ -348,6 +348,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
 // ago has landed"; the wait that retires a half-tile sits one barrier before its first read, and a half-tile
 // is re-staged at least two phases after its last read.
 //
+// That is SCHED 0, kept in the developer library for A/B runs.  SCHED 1, what the product runs, is the int8 kernel's
+// later form: TWO segments of 32 MFMAs per K-tile (half the barriers) and the two k-halves of an accumulator
+// issued back to back (less power per MFMA; the order of the sums inside an accumulator is unchanged, so the
+// results are bit-equal):
+//   S1: read W0(t) W1(t)    | DMA W0(t+1) W1(t+1) | vmcnt(2): X1(t) X0(t+1) landed   | barrier | 32 MFMAs | barrier
+//   S2: read X1(t) X0(t+1)  | DMA X1(t+1) X0(t+2) | vmcnt(4): W0(t+1) W1(t+1) landed | barrier | 32 MFMAs | barrier
+//
 // A weight half-tile keeps TWO 64-byte weight rows per 128-byte LDS row (row pair j = n >> 1; the 16-byte
 // chunk c of row n is logical slot q = (n & 1) * 4 + c, stored at slot q ^ ((j >> 1) & 3)): a 16-lane group
 // of a fragment read then touches 16 different 16-byte slots of the 256-byte bank row, as the activation
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
     } while (0)
 #define MIQ_W8F_WAIT_DMA() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 
-template <int OUT, int NP>
+template <int OUT, int NP, int SCHED = 1>
 __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
     constexpr int kXHalf = 128 * kTileK;            // 128 rows x 64 bf16
     constexpr int kWHalf = 64 * kTileK;             // 128 rows x 64 int8 = 64 row pairs
@@ -437,8 +444,12 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
     stage_w(b0 + 2 * kXHalf + kWHalf, wbase[1], 0);
     stage_x(b0 + kXHalf, xbase[1], 0);
     stage_x(b1, xbase[0], 1);
-    stage_w(b1 + 2 * kXHalf, wbase[0], 1);
-    MIQ_W8F_WAIT_DMA();
+    if constexpr (SCHED == 0) {
+        stage_w(b1 + 2 * kXHalf, wbase[0], 1);
+        MIQ_W8F_WAIT_DMA();
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X0(0), W0(0), W1(0) landed; X1(0), X0(1) in flight
+    }
     MIQ_W8F_BARRIER();
     if (wm == 1) MIQ_W8F_BARRIER();
 
@@ -458,19 +469,62 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
             for (int i = 0; i < 4; ++i) f[e][i] = __builtin_bit_cast(v8bf, lds_read16(half + x_frag + i * 16 * kTileK + xlo[e]));
     };
     auto mma = [&](v4f (&c)[4][2], const v8bf (&f)[2][4], const v8bf (&wf)[2][2]) {
+        if constexpr (SCHED == 0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+        } else {
+            // the two k-halves of an accumulator back to back, the weight fragment alternating 0 1 1 0 (pinned with
+            // scheduling barriers: left alone the compiler restores the k-major order)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = (i & 1) ? 1 - jj : jj;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
     };
 
     read_x(xf, b0);   // X0(0)
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * kBuf;
         char* nxt = smem + ((t + 1) & 1) * kBuf;
+
+        if constexpr (SCHED == 1) {
+            read_w(wf0, cur + 2 * kXHalf);
+            read_w(wf1, cur + 2 * kXHalf + kWHalf);
+            stage_w(nxt + 2 * kXHalf, wbase[0], t + 1);
+            stage_w(nxt + 2 * kXHalf + kWHalf, wbase[1], t + 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // X1(t), X0(t+1)
+            MIQ_W8F_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[0][0], xf, wf0);
+            mma(acc[0][1], xf, wf1);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_W8F_BARRIER();
+
+            read_x(xf2, cur + kXHalf);
+            read_x(xf, nxt);
+            stage_x(nxt + kXHalf, xbase[1], t + 1);
+            stage_x(cur, xbase[0], t + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // W0(t+1), W1(t+1)
+            MIQ_W8F_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            mma(acc[1][1], xf2, wf1);
+            mma(acc[1][0], xf2, wf0);
+            __builtin_amdgcn_s_setprio(0);
+            MIQ_W8F_BARRIER();
+            continue;
+        }
 
         read_w(wf0, cur + 2 * kXHalf);
         stage_w(nxt + 2 * kXHalf + kWHalf, wbase[1], t + 1);
@@ -694,6 +748,10 @@ int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t 
         a.tiles_n = static_cast<int>(ceil_div(g.N, 256));
         constexpr int kLds = 2 * (2 * 128 + 2 * 64) * kTileK;
         auto kern = gemm_w8f_256_kernel<OUT, NP>;
+#ifndef MIQ_NO_DEV_SWITCHES
+        if (const char* sc = dev_switch("MIQ_W8F_SCHED"))   // developer A/B switch: 0 = the four-phase schedule
+            if (sc[0] == '0') kern = gemm_w8f_256_kernel<OUT, NP, 0>;
+#endif
         if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
         kern<<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
         return check_launch("gemm_w8f_256_kernel");

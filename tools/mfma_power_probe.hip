@@ -28,6 +28,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // MODE 2: the two k-steps of an accumulator back to back
 // MODE 3: MODE 2 with the alternating weight fragment
 // MODE 4: four k-steps of an accumulator back to back (operands of k-steps 2, 3 = those of 0, 1 swapped around)
+// MODE 8: MODE 3 with the k-step order alternating 0 1 / 1 0 from one accumulator to the next (every MFMA then shares its
+//         accumulator or one operand with the one before it)
 // MODE 5: 32x32x32, 2 x 1 accumulators of 16 registers, four k-steps, k-step-major
 // MODE 6: 32x32x32, the four k-steps of an accumulator back to back
 // MODE 7: 32x32x32, 2 x 2 accumulators, two k-steps, k-step-major
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(512) void probe(const v4i* __restrict__ src, int it
 #pragma unroll
         for (int j = 0; j < 2; ++j) w[ks][j] = src[(ks * 6 + 4 + j) * 64 + lane];
     }
-    if constexpr (MODE <= 4) {
+    if constexpr (MODE <= 4 || MODE == 8) {
         v4i c[4][2] = {};
         for (int it = 0; it < iters; ++it) {
             if constexpr (MODE == 0 || MODE == 1) {
@@ -61,9 +63,10 @@ __global__ __launch_bounds__(512) void probe(const v4i* __restrict__ src, int it
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const int j = (MODE == 3 && (i & 1)) ? 1 - jj : jj;
+                        const int j = ((MODE == 3 || MODE == 8) && (i & 1)) ? 1 - jj : jj;
 #pragma unroll
-                        for (int ks = 0; ks < (MODE == 4 ? 4 : 2); ++ks) {
+                        for (int kk = 0; kk < (MODE == 4 ? 4 : 2); ++kk) {
+                            const int ks = (MODE == 8 && ((i * 2 + jj) & 1)) ? 1 - kk : kk;
                             c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[ks & 1][j ^ (ks >> 1)], a[ks & 1][i ^ (ks >> 1)], c[i][j], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -182,6 +185,7 @@ int main() {
             run<2>(d.p, sink, iters, "16x16x64, two k-steps of an accumulator back to back", d.name);
             run<3>(d.p, sink, iters, "16x16x64, back to back + weight fragment 0 1 1 0", d.name);
             run<4>(d.p, sink, iters, "16x16x64, four k-steps of an accumulator back to back", d.name);
+            run<8>(d.p, sink, iters, "16x16x64, back to back, 0 1 1 0, k-steps 0 1 / 1 0", d.name);
             run<5>(d.p, sink, iters, "32x32x32, 2x1 accumulators, k-step-major", d.name);
             run<6>(d.p, sink, iters, "32x32x32, four k-steps of an accumulator back to back", d.name);
             run<7>(d.p, sink, iters, "32x32x32, 2x2 accumulators, k-step-major", d.name);
