@@ -462,7 +462,9 @@ def test_pool_rejects_bad_arguments():
 
 # ------------------------------------------------------------------------------ GEMM cut along M
 @pytest.mark.parametrize("M,Nn,K", [(2304, 8192, 272), (2100, 8192, 64), (4352, 8192, 128), (1280, 14336, 144),
-                                    (2304, 8190, 96)])
+                                    (2304, 8190, 96),
+                                    # 3.5 rounds of tiles (stay whole: a half-empty round costs half a round), 7 x 42 tiles
+                                    (2048, 28672, 80), (2048, 28500, 64), (1700, 10752, 48)])
 @pytest.mark.parametrize("od", [torch.int32, torch.float32, torch.bfloat16])
 def test_gemm_whole_rounds_plus_tail(N, M, Nn, K, od):
     """Tile counts a little over a multiple of the 256 CUs run as whole rounds of 256 x 256 tiles plus a second
