@@ -280,6 +280,7 @@ CONV_SHAPES = [
     (11, 64, 14, 14, 64, 3, 1, 1), (12, 128, 14, 14, 192, 3, 1, 1),
     # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
     (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
+    (2, 3, 30, 224, 64, 7, 2, 3),    # two 64-pixel blocks a row, the second ragged
 ]
 
 
@@ -357,7 +358,9 @@ def test_conv_resnet_layer_vs_torch(N):
                                               (5, 64, 20, 20, 70, 3, 1, 1), (3, 128, 28, 28, 24, 3, 1, 1),
                                               (5, 64, 20, 21, 16, 3, 1, 1),
                                               # strided 1 x 1: the subsampling re-layout
-                                              (2, 64, 16, 16, 70, 1, 2, 0), (2, 24, 9, 11, 12, 1, 2, 0)])
+                                              (2, 64, 16, 16, 70, 1, 2, 0), (2, 24, 9, 11, 12, 1, 2, 0),
+                                              # stems: the row-block kernel (fp32) beside the im2col-order one (bf16)
+                                              (2, 3, 45, 40, 80, 7, 2, 3), (1, 3, 18, 224, 64, 7, 2, 3)])
 def test_conv_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p):
     x, w = rand_i8((B, C, H, W), 9), rand_i8((Co, C, k, k), 10)
     g = torch.Generator().manual_seed(4)
