@@ -21,6 +21,7 @@
 
 #include "miq_common.h"
 #include "miq_gemm_core.h"
+#include "miq_patch.h"
 
 namespace {
 
@@ -43,46 +44,9 @@ struct ConvGeom {
     int64_t sub, Hs, Ws;
 };
 
-// conv3x3_patch_kernel's tile: kTM output pixels of one image x 64 output channels per workgroup; one stage =
-// the pixel patch of a 64-channel group (4 chunk planes of kPlaneSlots 16-byte slots) + that group's weights.
-constexpr int kTM = 448;                                // 28 fragments: 4 wave rows x 7
-constexpr int kPlaneSlots = 704;                        // >= (rows a tile touches + 2) * pitch + 2
 constexpr int kPatchBytes = 4 * kPlaneSlots * kChunk;   // 44 KiB
 constexpr int kWStageBytes = 9 * 4 * 64 * kChunk;       // 36 KiB: [tap][chunk][channel][16 B]
 constexpr int kPlanarStage = kPatchBytes + kWStageBytes;
-
-// How the patch kernel tiles an image of HoWo output pixels whose padded copy has Hp rows of `pitch` slots: tiles of kTM
-// consecutive pixels of one image (group = 1) if the padded rows a tile touches (+2) fit `slots` and the tiles are mostly
-// pixels, or, for images of at most half a tile, `group` whole images per tile (their padded copies are one run in memory).
-// False if neither fits.
-bool patch_tiling(int64_t HoWo, int64_t Wo, int64_t Hp, int64_t pitch, int64_t slots, int64_t& group) {
-    group = 1;
-    if (2 * HoWo <= kTM) {
-        group = std::min<int64_t>(kTM / HoWo, (slots - 2) / (Hp * pitch));
-        const bool ok = group >= 2 && 5 * group * HoWo >= 4 * kTM;   // ... and still mostly pixels
-        if (!ok) group = 1;
-        return ok;
-    }
-    int64_t rows = 0;
-    for (int64_t p0 = 0; p0 < HoWo; p0 += kTM) {
-        const int64_t p1 = std::min<int64_t>(p0 + kTM, HoWo) - 1;
-        rows = std::max(rows, p1 / Wo - p0 / Wo + 3);
-    }
-    const int64_t tiles_img = ceil_div(HoWo, kTM);
-    return rows * pitch + 2 <= slots && 5 * HoWo >= 4 * tiles_img * kTM;
-}
-
-// The fields of PlanarArgs that describe the units, from the tiling above.
-template <typename Args>
-void set_patch_units(Args& pa, int64_t B, int64_t HoWo, int64_t Hp, int64_t pitch, int64_t group) {
-    pa.group = (int)group;
-    pa.B = (int)B;
-    pa.img_slots = (int)(Hp * pitch);
-    pa.pix_end = (int)(group * HoWo);
-    pa.hw_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(HoWo)) + 1u;
-    pa.tiles_img = group > 1 ? 1 : (int)ceil_div(HoWo, kTM);
-    pa.units = (int)(ceil_div(B, group) * pa.tiles_img * pa.tiles_n);
-}
 
 bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
                int64_t pad, ConvGeom& g, bool relayout = true) {   // relayout = false: the caller's channels-last form is staged as it is
@@ -1073,18 +1037,6 @@ constexpr int kDirectStageBytes = 1792;   // 16 channels x cpc chunks of one wav
     if (g.stamps && threadIdx.x == 0 && stamp_it < 8)                                               \
         g.stamps[(static_cast<size_t>(blockIdx.x) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #endif
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 16] (the instruction takes an immediate).
-__device__ __forceinline__ void wait_vmcnt_upto16(int n) {
-    switch (__builtin_amdgcn_readfirstlane(n)) {
-#define MIQ_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        MIQ_VMCNT_CASE(1) MIQ_VMCNT_CASE(2) MIQ_VMCNT_CASE(3) MIQ_VMCNT_CASE(4) MIQ_VMCNT_CASE(5) MIQ_VMCNT_CASE(6)
-        MIQ_VMCNT_CASE(7) MIQ_VMCNT_CASE(8) MIQ_VMCNT_CASE(9) MIQ_VMCNT_CASE(10) MIQ_VMCNT_CASE(11) MIQ_VMCNT_CASE(12)
-        MIQ_VMCNT_CASE(13) MIQ_VMCNT_CASE(14) MIQ_VMCNT_CASE(15) MIQ_VMCNT_CASE(16)
-#undef MIQ_VMCNT_CASE
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
 
 // One persistent workgroup per CU (eight waves, 256 registers each, all of the CU's LDS) walks (image, tile, channel
 // tile) units (small images: a unit is `group` consecutive whole images, whose padded copies are one run in memory), with the phases of a stage overlapped in software:

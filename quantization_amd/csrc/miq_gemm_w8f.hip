@@ -22,9 +22,11 @@
 // 2*(lane>>4)+1 of sub-tile h.  The k order inside an MFMA never has to be known: both operands use
 // the same k -> (lane, slot) map.
 #include <algorithm>
+#include <type_traits>
 
 #include "miq_common.h"
 #include "miq_gemm_core.h"
+#include "miq_patch.h"
 
 namespace {
 
@@ -1058,6 +1060,430 @@ size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K, int planes) {
     return p.splits > 1 ? static_cast<size_t>(round_up(static_cast<int64_t>(p.splits) * M * N * 4, 256)) : 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// 3 x 3 / stride 1 layers: the pixel patch of a tile stays in LDS (the int8 convolution's conv3x3_patch_kernel,
+// miq_conv2d_i8.hip, carried over to the bf16 MFMA).
+//
+// In im2col order such a layer stages every activation byte nine times (64 -> 64 56x56 at batch 256, fp32: 9 taps x
+// 2 planes x 110 MB L2 -> LDS per call, which is what bounded it).  Here the padded copy is kept in CHUNK PLANES of eight
+// bf16 channels, xp[plane][b][hp][pitch][8] (row pitch a multiple of 4 slots), so the patch of 448 consecutive output
+// pixels of one image -- every padded row their windows touch -- is one contiguous run per plane, copied by LDS-DMA as it
+// lies; the convolution is then nine shifted GEMMs over the patch (fragment address = per-row base + the tap's uniform
+// shift), 32 "virtual" channels (four planes) per stage:
+//   * bf16 activations: group g = channels 32g .. 32g+31, plane 4g + q = channels 32g + 8q .. +7;
+//   * fp32 / fp16 activations: group g = channels 16g .. 16g+15 as hi and lo planes (hi = bf16(x), lo = bf16(x - hi)):
+//     planes 4g + {0, 1} = hi of channels 16g .. +7 / +8 .. +15, planes 4g + {2, 3} = lo of the same, and the weight
+//     fragment of k-group q is that of q & 1, so one MFMA sums (hi + lo) * w over sixteen channels.
+// The filters of a group sit beside the patch as [tap][k-group][output channel][8 bf16], widened from int8 (exactly) by
+// the filter re-layout, so a tap carries no conversion (widening in registers, as the GEMM kernels do, cost the taps
+// 40 vector instructions beside 14 MFMAs: 203 -> see profiles).  Everything else is the int8 kernel's structure: one persistent workgroup per CU (eight waves, 256
+// registers, two LDS stages), the next stage fetched piece by piece among the nine taps, tap t + 1's fragments read under
+// tap t's MFMAs, a finished unit's accumulators handed to a second register set and stored one fragment row per tap of
+// the next unit, one barrier per stage; small images take several whole images per tile.
+// ---------------------------------------------------------------------------------------
+constexpr int kPatchW8Bytes = 4 * kPlaneSlots * kChunk;   // 44 KiB: four planes of a group
+
+struct PatchW8Args {
+    const void* xp;       // chunk planes
+    const void* wp;       // [Cout / 64][groups][tap][k-group][64][8 bf16]
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int Cout, ncg, tiles_n, tiles_img, units;
+    int pitch, Hp, Wo, HoWo;
+    uint32_t ptot;        // slots of one chunk plane: B * Hp * pitch
+    uint32_t wo_magic, hw_magic;
+    uint32_t xp_bytes, wp_bytes;
+    int group, B, img_slots, pix_end;
+};
+
+// NCHW activation -> chunk planes (zero border, zero slots behind a row's last pixel).  One thread per eight channels of
+// one padded pixel: its eight loads run along pixels with its neighbours' (coalesced per channel plane), its one or two
+// 16-byte stores are consecutive with theirs.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void patch_w8_prep_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, int Cin, int H,
+                                                            int W, int Hp, int pitch, int pad, uint32_t ptot, uint32_t total) {
+    const uint32_t c8n = static_cast<uint32_t>(Cin) >> 3;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += 256u * gridDim.x) {
+        const uint32_t c8 = idx / ptot, slot = idx - c8 * ptot;          // channel octet, flat padded pixel
+        const uint32_t rowi = slot / pitch, s = slot - rowi * pitch;    // b * Hp + hp, column
+        const uint32_t b = rowi / Hp, hp = rowi - b * Hp;
+        const int h = static_cast<int>(hp) - pad, w = static_cast<int>(s) - pad;
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const T* src = x + ((static_cast<size_t>(b) * Cin + c8 * 8) * H + h) * W + w;
+            const size_t cs = static_cast<size_t>(H) * W;
+            float fh[8], fl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = to_f32(src[j * cs]);
+                fh[j] = bf16_round(v);
+                if constexpr (NP == 2) {
+                    if (__builtin_isinf(fh[j]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
+                        fh[j] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+                    fl[j] = (__builtin_isinf(fh[j]) || fh[j] != fh[j]) ? 0.0f : __fsub_rn(v, fh[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = pack2_bf16(fh[2 * j], fh[2 * j + 1]);
+                if constexpr (NP == 2) lo[j] = pack2_bf16(fl[2 * j], fl[2 * j + 1]);
+            }
+        }
+        // plane of the hi chunk: bf16: the octet itself; two planes: group c8 >> 1, k-group c8 & 1 (lo: + 2)
+        const uint32_t plane = NP == 1 ? c8 : (c8 >> 1) * 4 + (c8 & 1);
+        uint4* o = reinterpret_cast<uint4*>(xp) + static_cast<size_t>(plane) * ptot + slot;
+        *o = uint4{hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (NP == 2) o[2 * static_cast<size_t>(ptot)] = uint4{lo[0], lo[1], lo[2], lo[3]};
+    }
+    (void)c8n;
+}
+
+// OIHW int8 (3 x 3) -> wp[Cout / 64][groups][tap][k-group][channel % 64][8 bf16]: per 64-output-channel tile and group
+// one contiguous image of the LDS weight stage (zero past Cout), already widened to bf16 (exact) so that the kernel's
+// taps carry no conversion.  One item per 16-byte chunk: eight consecutive input channels of one tap.
+template <int NP>
+__global__ __launch_bounds__(256) void patch_w8_pack_kernel(const int8_t* __restrict__ w, uint4* __restrict__ wp,
+                                                            uint32_t total_chunks, int Cin, int Cout) {
+    constexpr uint32_t NQ = NP == 1 ? 4 : 2, CPG = NQ * 8;   // k-groups and channels of a group
+    const uint32_t ncg = static_cast<uint32_t>(Cin) / CPG;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total_chunks; idx += 256u * gridDim.x) {
+        const uint32_t nl = idx & 63;
+        uint32_t rest = idx >> 6;
+        const uint32_t q = rest % NQ;
+        rest /= NQ;
+        const uint32_t tap = rest % 9, grp = rest / 9, cg = grp % ncg, n = (grp / ncg) * 64 + nl;
+        const uint32_t c = cg * CPG + q * 8;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (n < static_cast<uint32_t>(Cout)) {
+            const int8_t* src = w + (static_cast<size_t>(n) * Cin + c) * 9 + tap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pack2_bf16(static_cast<float>(src[(2 * j) * 9]), static_cast<float>(src[(2 * j + 1) * 9]));
+        }
+        wp[idx] = uint4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <int OUT, int NP, bool STREAM>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g) {
+    constexpr int FM = 7, FN = 2;
+    constexpr int NQ = NP == 1 ? 4 : 2;                  // k-groups of the weight stage
+    constexpr int kWst = 9 * NQ * 64 * kChunk;           // bytes of one weight stage (bf16)
+    constexpr int kWInstr = kWst / 1024;                 // wave-instructions that fetch it (36 or 18)
+    constexpr int kPatch = kPatchW8Bytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, [2] weight stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+    // Filters stay resident when those of all the layer's groups fit beside the two patches (up to 72 KiB: 64 input
+    // channels): a workgroup keeps one channel tile, so they are fetched once; otherwise a group's filters travel with
+    // its patch, stage by stage.
+    const bool w_res = g.ncg * kWst <= 160 * 1024 - 2 * kPatch;
+
+    struct Unit {
+        uint32_t b, p0, y0, tn;
+    };
+    auto decode = [&](int unit) {
+        Unit u;
+        u.tn = static_cast<uint32_t>(unit % g.tiles_n);
+        const uint32_t t = static_cast<uint32_t>(unit / g.tiles_n);
+        const uint32_t bi = t / g.tiles_img;
+        u.b = bi * g.group;
+        u.p0 = (t - bi * g.tiles_img) * kTM;
+        u.y0 = u.p0 / g.Wo;
+        return u;
+    };
+    // One stage's fetch is 44 wave-instructions of patch and kWInstr of weights, dealt over the eight waves: piece k of a
+    // wave is patch instruction wave + 8k (k < 6) and weight instruction wave + 8k.  Returns whether it issued any.
+    auto issue_piece = [&](const Unit& u, int cg, int buf, bool weights, int k) -> bool {
+        bool any = false;
+        const int q = wave + 8 * k;
+        if (q < 44) {
+            const uint32_t first = (u.b * g.Hp + u.y0) * g.pitch;
+            const int plane = q / 11, seg = q - plane * 11;
+            const uint32_t off = ((static_cast<uint32_t>(cg) * 4 + plane) * g.ptot + first + seg * 64 + lane) * kChunk;
+            dma16(rx, smem + buf * kPatch + plane * (kPlaneSlots * kChunk) + seg * 1024, off);
+            any = true;
+        }
+        if (weights && q < kWInstr) {
+            dma16(rw, smem + 2 * kPatch + (w_res ? cg : buf) * kWst + q * 1024,
+                  ((u.tn * g.ncg + cg) * kWInstr + q) * 1024 + lane * kChunk);
+            any = true;
+        }
+        return any;
+    };
+
+    // per-channel epilogue parameters of this workgroup's channel tile, once
+    const int tn_mine = static_cast<int>(blockIdx.x) % g.tiles_n;
+    float al[FN], bi[FN];
+#pragma unroll
+    for (int c = 0; c < FN; ++c) {
+        const int n = tn_mine * 64 + wn * 32 + c * 16 + (lane & 15);
+        al[c] = 1.f;
+        bi[c] = 0.f;
+        if (n < g.Cout) {
+            al[c] = g.alpha[n];
+            if (g.bias) bi[c] = g.bias[n];
+        }
+    }
+
+    v4f acc[FM][FN], done[FM][FN];   // the unit being accumulated; the finished one on its way out
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = done[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int kEsz = OUT == kOutBF16 ? 2 : 4;
+    constexpr int kNt = STREAM ? 2 : 0;   // cache policy of the output stores: 2 = nontemporal
+    // One fragment row of the finished unit, as buffer stores into the unit's image(s): a lane with nothing to store
+    // gets an offset past the buffer, which the hardware drops (no branch: the count of store instructions is a constant).
+    auto store_row = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto I) -> int {
+        constexpr int i = decltype(I)::value;
+        const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4;   // HoWo % 4 == 0: four pixels in or out together
+        const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;
+        const uint32_t at = im * g.Cout * g.HoWo + pp;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+            v4f a = done[i][j];
+            asm volatile("" : "+v"(a));   // (opaque: the conversion stays beside the tap it was written for)
+            const uint32_t off = p < static_cast<uint32_t>(g.pix_end) && n < g.Cout ? (n * g.HoWo + at) * kEsz : kOob;
+            const float y0 = dequant1f(a[0], bi[j], al[j], g.beta), y1 = dequant1f(a[1], bi[j], al[j], g.beta);
+            const float y2 = dequant1f(a[2], bi[j], al[j], g.beta), y3 = dequant1f(a[3], bi[j], al[j], g.beta);
+            if constexpr (OUT == kOutF32) {
+                __builtin_amdgcn_raw_buffer_store_b128(v4i{__float_as_int(y0), __float_as_int(y1), __float_as_int(y2), __float_as_int(y3)},
+                                                       r, off, 0, kNt);
+            } else {
+                const uint2 h = pack4_bf16(y0, y1, y2, y3);
+                __builtin_amdgcn_raw_buffer_store_b64(v2u{h.x, h.y}, r, off, 0, kNt);
+            }
+        }
+        return FN;
+    };
+    auto store_step = [&](__amdgpu_buffer_rsrc_t r, const Unit& u, auto T) -> int {
+        if constexpr (decltype(T)::value >= FM)
+            return 0;
+        else
+            return store_row(r, u, T);
+    };
+    const uint32_t img_bytes = static_cast<uint32_t>(g.Cout) * g.HoWo * kEsz;
+    auto image_of = [&](const Unit& u) {   // (the unit's images that exist: stores to one past the batch are dropped)
+        const uint32_t n = static_cast<uint32_t>(g.B) - u.b < static_cast<uint32_t>(g.group) ? g.B - u.b : g.group;
+        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, n * img_bytes);
+    };
+
+    // weight fragment of k-group lane >> 4 (two planes: of (lane >> 4) & 1): eight bf16 per lane
+    const int w_lane = ((((lane >> 4) & (NQ - 1)) * 64) + wn * 32 + (lane & 15)) * kChunk;
+
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the second wave of a SIMD goes first whenever both want to issue
+    int unit = blockIdx.x;
+    Unit cur = decode(unit);
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) (void)issue_piece(cur, 0, 0, true, k);
+    if (w_res) {   // the other groups' filters
+#pragma unroll 1
+        for (int cg = 1; cg < g.ncg; ++cg)
+            for (int q = wave; q < kWInstr; q += 8)
+                dma16(rw, smem + 2 * kPatch + cg * kWst + q * 1024, ((cur.tn * g.ncg + cg) * kWInstr + q) * 1024 + lane * kChunk);
+    }
+    int buf = 0;
+    int stores = 0;         // store instructions this wave issued after its last piece of the next stage's fetch
+    bool pending = false;   // `done` holds a unit that has not left yet
+    Unit prev{};
+    __amdgpu_buffer_rsrc_t rout = image_of(cur);
+    for (; unit < g.units; unit += gridDim.x) {
+        cur = decode(unit);
+        int aoff[FM];   // patch address of each fragment row this lane supplies: plane lane>>4, pixel (y - y0) * pitch + x
+        {
+            uint32_t qfirst = cur.p0 + wm * FM * 16 + (lane & 15);
+            asm volatile("" : "+v"(qfirst));
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                uint32_t p = qfirst + i * 16;
+                if (p >= static_cast<uint32_t>(g.pix_end)) p = g.pix_end - 1;   // rows past the unit: computed, never stored
+                const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;
+                const uint32_t y = __umulhi(pp, g.wo_magic), x = pp - y * g.Wo;
+                aoff[i] = (lane >> 4) * (kPlaneSlots * kChunk) + (im * g.img_slots + (y - cur.y0) * g.pitch + x) * kChunk;
+            }
+        }
+        for (int cg = 0; cg < g.ncg; ++cg) {
+            // This wave's pieces of the stage have landed once all but the stores it issued after the last of them are
+            // done; the barrier tells the same of the other waves' pieces, and that every wave has left the stage before.
+            wait_vmcnt_upto16(stores);
+            stores = 0;
+            __syncthreads();
+            int ncg = cg + 1, nunit = unit;
+            if (ncg == g.ncg) {
+                ncg = 0;
+                nunit = unit + gridDim.x;
+            }
+            const bool fetch = nunit < g.units;
+            const Unit nxt = decode(fetch ? nunit : unit);
+            const bool flush = pending && cg == 0;
+            const char* patch = smem + buf * kPatch;
+            const char* wst = smem + 2 * kPatch + (w_res ? cg : buf) * kWst + w_lane;
+            {
+                v8bf af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
+                auto read_tap = [&](auto S, int kh, int kw) {
+                    constexpr int s = decltype(S)::value;
+                    const char* arow = patch + (kh * g.pitch + kw) * kChunk;
+                    const char* wrow = wst + (kh * 3 + kw) * (NQ * 64 * kChunk);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) wf[s][j] = __builtin_bit_cast(v8bf, lds_read16(wrow + j * 16 * kChunk));
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[s][i] = __builtin_bit_cast(v8bf, lds_read16(arow + aoff[i]));
+                };
+                auto tap = [&](auto T) {
+                    constexpr int t = decltype(T)::value, s = t & 1;
+                    if constexpr (t < 6) {
+                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_res, t)) stores = 0;
+                    }
+                    if constexpr (t + 1 < 9) read_tap(std::integral_constant<int, (t + 1) & 1>{}, (t + 1) / 3, (t + 1) % 3);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][i], wf[s][j], acc[i][j], 0, 0, 0);
+                    // the finished unit's row t leaves behind this tap's MFMAs, as a block of its own behind a branch
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (flush) stores += store_step(rout, prev, T);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                read_tap(std::integral_constant<int, 0>{}, 0, 0);
+                tap(std::integral_constant<int, 0>{});
+                tap(std::integral_constant<int, 1>{});
+                tap(std::integral_constant<int, 2>{});
+                tap(std::integral_constant<int, 3>{});
+                tap(std::integral_constant<int, 4>{});
+                tap(std::integral_constant<int, 5>{});
+                tap(std::integral_constant<int, 6>{});
+                tap(std::integral_constant<int, 7>{});
+                tap(std::integral_constant<int, 8>{});
+            }
+            if (flush) pending = false;
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                done[i][j] = acc[i][j];
+                acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        prev = cur;
+        rout = image_of(prev);
+        pending = true;
+    }
+    if (pending) {
+        (void)store_step(rout, prev, std::integral_constant<int, 0>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 1>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 2>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 3>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 4>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 5>{});
+        (void)store_step(rout, prev, std::integral_constant<int, 6>{});
+    }
+}
+
+// Geometry of the patch path, or ok = false when the layer does not take it: 3 x 3 / stride 1, whole 32-channel groups,
+// four output pixels per 16-byte store, enough pixels for every CU, and a patch that fits the LDS planes.
+struct PatchW8Geom {
+    bool ok;
+    int64_t Hp, Wp, pitch, Ho, Wo, ptot, group, ncg;
+    int64_t xp_bytes, wp_bytes;
+};
+
+PatchW8Geom make_patch_w8_geom(int planes, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW,
+                               int64_t stride, int64_t pad) {
+    PatchW8Geom p{};
+    const char* sw = dev_switch("MIQ_CONV_W8_PATCH");   // developer A/B switch: 0 = im2col-order kernel for every layer
+    if (KH != 3 || KW != 3 || stride != 1 || Cin % 32 != 0 || Cout <= 0 || (sw && sw[0] == '0')) return p;
+    p.Hp = H + 2 * pad;
+    p.Wp = W + 2 * pad;
+    if (p.Hp < 3 || p.Wp < 3) return p;
+    p.Ho = p.Hp - 2;
+    p.Wo = p.Wp - 2;
+    const int64_t HoWo = p.Ho * p.Wo;
+    if (HoWo % 4 != 0 || B * HoWo < 4 * kTM || HoWo >= 65536 || B >= 65536) return p;
+    p.pitch = round_up(p.Wp, 4);
+    p.ptot = B * p.Hp * p.pitch;
+    if (!patch_tiling(HoWo, p.Wo, p.Hp, p.pitch, kPlaneSlots, p.group)) return p;
+    const int64_t cpg = planes == 1 ? 32 : 16;
+    p.ncg = Cin / cpg;
+    p.xp_bytes = (Cin / 8) * planes * p.ptot * kChunk;
+    p.wp_bytes = ceil_div(Cout, 64) * p.ncg * (9 * (planes == 1 ? 4 : 2) * 64 * kChunk);
+    // 31-bit offsets: the planes, the packed filters, one image (or `group` images) of output, the tile count
+    if (p.xp_bytes >= (1ll << 31) || p.wp_bytes >= (1ll << 31) || p.group * Cout * HoWo * 4 >= (1ll << 31) ||
+        ceil_div(B, p.group) * ceil_div(HoWo, kTM) * ceil_div(Cout, 64) >= (1ll << 31))
+        return p;
+    p.ok = true;
+    return p;
+}
+
+template <int OUT, int NP>
+int launch_patch_w8(const PatchW8Args& a, bool stream_out, hipStream_t st) {
+    void (*kern)(PatchW8Args) = conv3x3_patch_w8_kernel<OUT, NP, false>;
+    if (stream_out) kern = conv3x3_patch_w8_kernel<OUT, NP, true>;
+    constexpr int kWst = 9 * (NP == 1 ? 4 : 2) * 64 * kChunk;
+    static_assert(2 * kPatchW8Bytes + 2 * kWst <= 160 * 1024, "LDS of one CU");
+    // two filter stages, or every group's filters when they fit (the kernel makes the same choice)
+    const int kLds = 2 * kPatchW8Bytes + (a.ncg * kWst <= 160 * 1024 - 2 * kPatchW8Bytes ? std::max(a.ncg, 2) : 2) * kWst;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    int grid = a.units < 256 ? a.units : 256 - 256 % a.tiles_n;   // one persistent workgroup per CU, each keeping one channel tile
+    if (grid < a.tiles_n) grid = a.units < a.tiles_n ? a.units : a.tiles_n;
+    kern<<<grid, 512, kLds, st>>>(a);
+    return check_launch("conv3x3_patch_w8_kernel");
+}
+
+// The whole patch path: re-layout into chunk planes, filter re-layout, the kernel.  `workspace` holds xp_bytes (rounded
+// up to 256) + wp_bytes.
+int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                 int64_t Cout, int64_t pad, const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                 void* workspace, hipStream_t st) {
+    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    uint16_t* xp = static_cast<uint16_t*>(workspace);
+    uint4* wp = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
+    const int64_t items = (Cin / 8) * P.ptot;   // one thread per channel octet and padded pixel
+    MIQ_REQUIRE(items < (1ll << 32), MIQ_ERANGE, "miq_conv2d_w8: too many padded pixels for the chunk-plane re-layout");
+    const int pgrid = static_cast<int>(std::min<int64_t>(ceil_div(items, 256), 1 << 20));
+#define MIQ_PATCH_PREP(T, NP)                                                                                              \
+    patch_w8_prep_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp,   \
+                                                       (int)P.pitch, (int)pad, (uint32_t)P.ptot, (uint32_t)items)
+    if (x_dtype == MIQ_F32)
+        MIQ_PATCH_PREP(float, 2);
+    else if (x_dtype == MIQ_F16)
+        MIQ_PATCH_PREP(_Float16, 2);
+    else
+        MIQ_PATCH_PREP(__bf16, 1);
+#undef MIQ_PATCH_PREP
+    if (int rc = check_launch("patch_w8_prep_kernel")) return rc;
+    const uint32_t wtotal = static_cast<uint32_t>(P.wp_bytes / kChunk);
+    const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
+    if (planes == 1)
+        patch_w8_pack_kernel<1><<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
+    else
+        patch_w8_pack_kernel<2><<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
+    if (int rc = check_launch("patch_w8_pack_kernel")) return rc;
+
+    PatchW8Args a{};
+    a.xp = xp; a.wp = wp; a.bias = bias; a.alpha = alpha; a.out = out; a.beta = beta;
+    a.Cout = (int)Cout; a.ncg = (int)P.ncg; a.tiles_n = (int)ceil_div(Cout, 64);
+    a.pitch = (int)P.pitch; a.Hp = (int)P.Hp; a.Wo = (int)P.Wo; a.HoWo = (int)(P.Ho * P.Wo);
+    a.ptot = (uint32_t)P.ptot;
+    a.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(P.Wo)) + 1u;
+    a.xp_bytes = (uint32_t)P.xp_bytes; a.wp_bytes = (uint32_t)P.wp_bytes;
+    set_patch_units(a, B, P.Ho * P.Wo, P.Hp, P.pitch, P.group);
+    const int64_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    const bool stream_out = B * Cout * P.Ho * P.Wo * esz >= (192ll << 20) && out_dtype != MIQ_BF16;
+#define MIQ_PATCH_RUN(NP) \
+    (out_dtype == MIQ_F32 ? launch_patch_w8<kOutF32, NP>(a, stream_out, st) : launch_patch_w8<kOutBF16, NP>(a, false, st))
+    return planes == 1 ? MIQ_PATCH_RUN(1) : MIQ_PATCH_RUN(2);
+#undef MIQ_PATCH_RUN
+}
+
 }  // namespace
 
 extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
@@ -1146,6 +1572,8 @@ extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, i
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvW8Geom G;
     if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
+    const PatchW8Geom P = make_patch_w8_geom(x_dtype == MIQ_BF16 ? 1 : 2, B, Cin, H, W, Cout, KH, KW, stride, pad);
+    if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256) + round_up(P.wp_bytes, 256));
     return static_cast<size_t>((x_dtype == MIQ_BF16 ? 1 : 2) * G.plane_bytes + G.wp_bytes);
 }
 
@@ -1176,6 +1604,15 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
                 need, workspace_bytes);
     MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_w8: workspace must be 256-byte aligned");
     hipStream_t st = miq::as_stream(stream);
+    // 3 x 3 / stride 1 over whole 32-channel groups: the kernel that keeps a tile's pixel patch in LDS (16-byte stores
+    // of four fp32 pixels / 8-byte stores of four bf16 pixels need the output aligned to them)
+    {
+        const PatchW8Geom P = make_patch_w8_geom(planes, B, Cin, H, W, Cout, KH, KW, stride, pad);
+        if (P.ok) {
+            MIQ_REQUIRE(miq::aligned(out, 4 * esz), MIQ_EALIGN, "miq_conv2d_w8: out must be aligned to four of its elements");
+            return run_patch_w8(P, x, x_dtype, w, B, Cin, H, W, Cout, pad, bias, alpha, beta, out, out_dtype, workspace, st);
+        }
+    }
     H = G.H; W = G.W; stride = G.stride;   // a subsampled 1 x 1 layer continues as its stride-1 equivalent
 
     uint16_t* xp = static_cast<uint16_t*>(workspace);

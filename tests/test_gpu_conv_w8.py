@@ -78,6 +78,43 @@ def test_conv_w8_resnet_layer(N):
     check(N, 32, 128, 28, 28, 128, 3, 1, 1, "bf16", seed=10)
 
 
+# 3 x 3 / stride 1 over whole 32-channel groups, Ho*Wo % 4 == 0 and images that fill 448-pixel tiles: the LDS-resident-patch
+# kernel (a partial last tile, ragged output channels, one to six channel groups, pad 0 / 1 / 2, an odd width, several
+# small images per tile with a last tile of one image, several channel tiles)
+PATCH_CASES = [
+    (3, 128, 28, 28, 70, 3, 1, 1), (5, 64, 20, 20, 64, 3, 1, 1), (5, 64, 22, 22, 32, 3, 1, 0), (2, 96, 42, 42, 70, 3, 1, 1),
+    (5, 32, 18, 18, 64, 3, 1, 2), (2, 64, 56, 56, 8, 3, 1, 1), (5, 64, 20, 21, 16, 3, 1, 1), (11, 64, 14, 14, 64, 3, 1, 1),
+    (12, 128, 14, 14, 192, 3, 1, 1), (40, 32, 8, 8, 64, 3, 1, 1), (5, 64, 30, 28, 192, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", PATCH_CASES)
+def test_conv_w8_patch_kernel_shapes(N, B, C, H, W, Co, k, s, p, xdt):
+    check(N, B, C, H, W, Co, k, s, p, xdt, seed=B * 7 + C + Co)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "bf16"])
+def test_conv_w8_patch_kernel_bf16_out_no_bias(N, xdt):
+    check(N, 6, 64, 20, 20, 72, 3, 1, 1, xdt, seed=5, bias=False, out_dtype=torch.bfloat16, beta=0.5)
+
+
+def test_conv_w8_patch_kernel_integer_activations_are_exact(N):
+    """Integer-valued activations: every product and every partial sum is exact in fp32, so the patch kernel, whatever
+    the order of its sums, must give the exact convolution and the oracle's epilogue of it bit for bit."""
+    from oracle import oracle_c as OC
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W, Co = 5, 64, 20, 20, 70
+    x = torch.randint(-8, 9, (B, C, H, W), generator=g).float()
+    w = torch.randint(-128, 128, (Co, C, 3, 3), generator=g, dtype=torch.int32).to(torch.int8)
+    alpha, bias = torch.rand(Co, generator=g) * 0.02 + 1e-4, torch.randn(Co, generator=g) * 5
+    acc = F.conv2d(x.double(), w.double(), padding=1).to(torch.int32).numpy()
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), 0.25)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        y = N.conv2d_w8(x.to(dt).cuda(), w.cuda(), 1, 1, bias=bias.cuda(), alpha=alpha.cuda(), beta=0.25)
+        np.testing.assert_array_equal(y.cpu().numpy(), ref)
+
+
 def test_conv_w8_1x1_strided_random_shapes(N):
     """Seeded random 1 x 1 layers with stride 2..4 (the subsampling re-layout) on all three activation types."""
     rng = np.random.default_rng(78)
