@@ -1102,10 +1102,9 @@ struct PatchW8Args {
 // one padded pixel: its eight loads run along pixels with its neighbours' (coalesced per channel plane), its one or two
 // 16-byte stores are consecutive with theirs.
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void patch_w8_prep_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, int Cin, int H,
-                                                            int W, int Hp, int pitch, int pad, uint32_t ptot, uint32_t total) {
-    const uint32_t c8n = static_cast<uint32_t>(Cin) >> 3;
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += 256u * gridDim.x) {
+__device__ __forceinline__ void patch_w8_prep_items(const T* __restrict__ x, uint16_t* __restrict__ xp, int Cin, int H, int W, int Hp,
+                                                    int pitch, int pad, uint32_t ptot, uint32_t total, uint32_t first, uint32_t step) {
+    for (uint32_t idx = first; idx < total; idx += step) {
         const uint32_t c8 = idx / ptot, slot = idx - c8 * ptot;          // channel octet, flat padded pixel
         const uint32_t rowi = slot / pitch, s = slot - rowi * pitch;    // b * Hp + hp, column
         const uint32_t b = rowi / Hp, hp = rowi - b * Hp;
@@ -1137,18 +1136,17 @@ __global__ __launch_bounds__(256) void patch_w8_prep_kernel(const T* __restrict_
         *o = uint4{hi[0], hi[1], hi[2], hi[3]};
         if constexpr (NP == 2) o[2 * static_cast<size_t>(ptot)] = uint4{lo[0], lo[1], lo[2], lo[3]};
     }
-    (void)c8n;
 }
 
 // OIHW int8 (3 x 3) -> wp[Cout / 64][groups][tap][k-group][channel % 64][8 bf16]: per 64-output-channel tile and group
 // one contiguous image of the LDS weight stage (zero past Cout), already widened to bf16 (exact) so that the kernel's
 // taps carry no conversion.  One item per 16-byte chunk: eight consecutive input channels of one tap.
 template <int NP>
-__global__ __launch_bounds__(256) void patch_w8_pack_kernel(const int8_t* __restrict__ w, uint4* __restrict__ wp,
-                                                            uint32_t total_chunks, int Cin, int Cout) {
+__device__ __forceinline__ void patch_w8_pack_items(const int8_t* __restrict__ w, uint4* __restrict__ wp, uint32_t total_chunks,
+                                                    int Cin, int Cout, uint32_t first, uint32_t step) {
     constexpr uint32_t NQ = NP == 1 ? 4 : 2, CPG = NQ * 8;   // k-groups and channels of a group
     const uint32_t ncg = static_cast<uint32_t>(Cin) / CPG;
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total_chunks; idx += 256u * gridDim.x) {
+    for (uint32_t idx = first; idx < total_chunks; idx += step) {
         const uint32_t nl = idx & 63;
         uint32_t rest = idx >> 6;
         const uint32_t q = rest % NQ;
@@ -1163,6 +1161,19 @@ __global__ __launch_bounds__(256) void patch_w8_pack_kernel(const int8_t* __rest
         }
         wp[idx] = uint4{v[0], v[1], v[2], v[3]};
     }
+}
+
+// Both re-layouts in one launch: workgroups [0, n_prep) re-lay the activation, the n_pack after them the filters.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void patch_w8_prep_kernel(const T* __restrict__ x, uint16_t* __restrict__ xp, int Cin, int H,
+                                                            int W, int Hp, int pitch, int pad, uint32_t ptot, uint32_t total,
+                                                            int n_prep, const int8_t* __restrict__ w, uint4* __restrict__ wp,
+                                                            uint32_t total_chunks, int Cout) {
+    const int n_pack = static_cast<int>(gridDim.x) - n_prep;
+    if (static_cast<int>(blockIdx.x) < n_prep)
+        patch_w8_prep_items<T, NP>(x, xp, Cin, H, W, Hp, pitch, pad, ptot, total, blockIdx.x * 256u + threadIdx.x, 256u * n_prep);
+    else
+        patch_w8_pack_items<NP>(w, wp, total_chunks, Cin, Cout, (blockIdx.x - n_prep) * 256u + threadIdx.x, 256u * n_pack);
 }
 
 template <int OUT, int NP, bool STREAM>
@@ -1449,9 +1460,12 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
     const int64_t items = (Cin / 8) * P.ptot;   // one thread per channel octet and padded pixel
     MIQ_REQUIRE(items < (1ll << 32), MIQ_ERANGE, "miq_conv2d_w8: too many padded pixels for the chunk-plane re-layout");
     const int pgrid = static_cast<int>(std::min<int64_t>(ceil_div(items, 256), 1 << 20));
-#define MIQ_PATCH_PREP(T, NP)                                                                                              \
-    patch_w8_prep_kernel<T, NP><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp,   \
-                                                       (int)P.pitch, (int)pad, (uint32_t)P.ptot, (uint32_t)items)
+    const uint32_t wtotal = static_cast<uint32_t>(P.wp_bytes / kChunk);
+    const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
+#define MIQ_PATCH_PREP(T, NP)                                                                                                  \
+    patch_w8_prep_kernel<T, NP><<<pgrid + wgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp, \
+                                                               (int)P.pitch, (int)pad, (uint32_t)P.ptot, (uint32_t)items, pgrid, w, \
+                                                               wp, wtotal, (int)Cout)
     if (x_dtype == MIQ_F32)
         MIQ_PATCH_PREP(float, 2);
     else if (x_dtype == MIQ_F16)
@@ -1460,13 +1474,6 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
         MIQ_PATCH_PREP(__bf16, 1);
 #undef MIQ_PATCH_PREP
     if (int rc = check_launch("patch_w8_prep_kernel")) return rc;
-    const uint32_t wtotal = static_cast<uint32_t>(P.wp_bytes / kChunk);
-    const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
-    if (planes == 1)
-        patch_w8_pack_kernel<1><<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
-    else
-        patch_w8_pack_kernel<2><<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
-    if (int rc = check_launch("patch_w8_pack_kernel")) return rc;
 
     PatchW8Args a{};
     a.xp = xp; a.wp = wp; a.bias = bias; a.alpha = alpha; a.out = out; a.beta = beta;
