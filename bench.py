@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 dense peak of MI355X
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
 
 PREWARM_S = 0.3   # seconds of untimed load before the warm-up steps (clock ramp), reported as prewarm_s
@@ -284,6 +285,36 @@ def conv_int8(N_, dev):
         "layers": 20, "total_ms": round(cl_ms, 4), "TOPS": round(cl_ops / (cl_ms * 1e-3) / 1e12, 1),
         "images_per_s": round(B / (cl_ms * 1e-3)), "roofline": mfma_roofline(cl_ops, cl_ms),
         "hbm_GBps_on_algorithmic_bytes": round(cl_bytes / (cl_ms * 1e-3) / 1e9, 1)}
+    return res
+
+
+def conv_weight_only_float(N_, dev):
+    """The same twenty layers as the reference's weight-only Conv2d runs them (quant/Weight_Only/Quantizer.py:72-91): float
+    NCHW activations, int8 OIHW weights, fp32 out (miq_conv2d_w8): whole calls (re-layout launch + kernel), HIP events per
+    call, outputs rotating over three buffers.  TFLOP/s counts 2 flops per multiply-add of the convolution (the two bf16
+    planes of fp32 activations are twice that in MFMA work); roofline against the dense bf16 MFMA peak."""
+    B = 256
+    res = {"batch": B, "out_dtype": "float32"}
+    for dt in (torch.float32, torch.bfloat16):
+        total_ms, total_ops = 0.0, 0.0
+        for C, H, Co, k, s, p, times in RESNET18_CONVS:
+            x = torch.randn(B, C, H, H, device=dev).to(dt)
+            w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device=dev).to(torch.int8)
+            alpha = torch.rand(Co, device=dev) * 1e-3
+            Ho = (H + 2 * p - k) // s + 1
+            outs = [torch.empty(B, Co, Ho, Ho, device=dev) for _ in range(3)]
+            it = [0]
+
+            def step():
+                N_.conv2d_w8(x, w, s, p, alpha=alpha, out=outs[it[0] % 3])
+                it[0] += 1
+            ms = median_ms(step, 10, 5)
+            total_ms += ms * times
+            total_ops += 2.0 * B * Co * Ho * Ho * C * k * k * times
+            del x, w, outs
+        res[f"stack_{str(dt).split('.')[-1]}"] = {
+            "layers": 20, "total_ms": round(total_ms, 4), "TFLOPs": round(total_ops / (total_ms * 1e-3) / 1e12, 1),
+            "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms, PEAK_BF16_TFLOPS)}
     return res
 
 
@@ -599,6 +630,7 @@ def main():
             line["extra"]["llama3_8b_mlp_decode"] = llama8b_mlp_decode(N_, dev)
             line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
             line["extra"]["conv_int8"] = conv_int8(N_, dev)
+            line["extra"]["conv_weight_only_float"] = conv_weight_only_float(N_, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)

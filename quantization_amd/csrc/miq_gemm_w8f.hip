@@ -1096,6 +1096,7 @@ struct PatchW8Args {
     uint32_t wo_magic, hw_magic;
     uint32_t xp_bytes, wp_bytes;
     int group, B, img_slots, pix_end;
+    int ragged;           // HoWo % 4 != 0 (7 x 7 images): a lane's four pixels may lie in two images, stored one by one
 };
 
 // NCHW activation -> chunk planes (zero border, zero slots behind a row's last pixel).  One thread per eight channels of
@@ -1256,6 +1257,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
         const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4;   // HoWo % 4 == 0: four pixels in or out together
         const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;
         const uint32_t at = im * g.Cout * g.HoWo + pp;
+        if (g.ragged) {   // (wave-uniform) every pixel on its own: four times the store instructions, for small outputs only
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+                v4f a = done[i][j];
+                asm volatile("" : "+v"(a));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t pe = p + e, ime = __umulhi(pe, g.hw_magic), ppe = pe - ime * g.HoWo;
+                    const uint32_t off = pe < static_cast<uint32_t>(g.pix_end) && n < g.Cout ? ((ime * g.Cout + n) * g.HoWo + ppe) * kEsz : kOob;
+                    const float y = dequant1f(a[e], bi[j], al[j], g.beta);
+                    if constexpr (OUT == kOutF32)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(y), r, off, 0, kNt);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>(f32_to_bf16_bits(y)), r, off, 0, kNt);
+                }
+            }
+            return 4 * FN;
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
@@ -1400,7 +1420,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
 }
 
 // Geometry of the patch path, or ok = false when the layer does not take it: 3 x 3 / stride 1, whole 32-channel groups,
-// four output pixels per 16-byte store, enough pixels for every CU, and a patch that fits the LDS planes.
+// enough pixels for every CU, and a patch that fits the LDS planes.
 struct PatchW8Geom {
     bool ok;
     int64_t Hp, Wp, pitch, Ho, Wo, ptot, group, ncg;
@@ -1418,8 +1438,8 @@ PatchW8Geom make_patch_w8_geom(int planes, int64_t B, int64_t Cin, int64_t H, in
     p.Ho = p.Hp - 2;
     p.Wo = p.Wp - 2;
     const int64_t HoWo = p.Ho * p.Wo;
-    if (HoWo % 4 != 0 || B * HoWo < 4 * kTM || HoWo >= 65536 || B >= 65536) return p;
-    p.pitch = round_up(p.Wp, 4);
+    if (B * HoWo < 4 * kTM || HoWo >= 65536 || B >= 65536) return p;
+    p.pitch = p.Wp;   // (the re-layout writes pixel by pixel: no need for rows of whole dwords of pixels)
     p.ptot = B * p.Hp * p.pitch;
     if (!patch_tiling(HoWo, p.Wo, p.Hp, p.pitch, kPlaneSlots, p.group)) return p;
     const int64_t cpg = planes == 1 ? 32 : 16;
@@ -1482,6 +1502,7 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
     a.ptot = (uint32_t)P.ptot;
     a.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(P.Wo)) + 1u;
     a.xp_bytes = (uint32_t)P.xp_bytes; a.wp_bytes = (uint32_t)P.wp_bytes;
+    a.ragged = (P.Ho * P.Wo) % 4 != 0;
     set_patch_units(a, B, P.Ho * P.Wo, P.Hp, P.pitch, P.group);
     const int64_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
     const bool stream_out = B * Cout * P.Ho * P.Wo * esz >= (192ll << 20) && out_dtype != MIQ_BF16;
@@ -1616,7 +1637,8 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     {
         const PatchW8Geom P = make_patch_w8_geom(planes, B, Cin, H, W, Cout, KH, KW, stride, pad);
         if (P.ok) {
-            MIQ_REQUIRE(miq::aligned(out, 4 * esz), MIQ_EALIGN, "miq_conv2d_w8: out must be aligned to four of its elements");
+            MIQ_REQUIRE((P.Ho * P.Wo) % 4 != 0 || miq::aligned(out, 4 * esz), MIQ_EALIGN,
+                        "miq_conv2d_w8: out must be aligned to four of its elements");
             return run_patch_w8(P, x, x_dtype, w, B, Cin, H, W, Cout, pad, bias, alpha, beta, out, out_dtype, workspace, st);
         }
     }

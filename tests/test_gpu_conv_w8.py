@@ -85,6 +85,9 @@ PATCH_CASES = [
     (3, 128, 28, 28, 70, 3, 1, 1), (5, 64, 20, 20, 64, 3, 1, 1), (5, 64, 22, 22, 32, 3, 1, 0), (2, 96, 42, 42, 70, 3, 1, 1),
     (5, 32, 18, 18, 64, 3, 1, 2), (2, 64, 56, 56, 8, 3, 1, 1), (5, 64, 20, 21, 16, 3, 1, 1), (11, 64, 14, 14, 64, 3, 1, 1),
     (12, 128, 14, 14, 192, 3, 1, 1), (40, 32, 8, 8, 64, 3, 1, 1), (5, 64, 30, 28, 192, 3, 1, 1),
+    # images whose pixel count is not a multiple of 4 (pixels stored one by one): 7 x 7 (eight images a tile, a last tile
+    # of three), 9 x 9 from a 7 x 7 input with pad 2, 21 x 23
+    (43, 64, 7, 7, 70, 3, 1, 1), (40, 32, 7, 7, 64, 3, 1, 2), (5, 32, 21, 23, 64, 3, 1, 1),
 ]
 
 
@@ -97,6 +100,7 @@ def test_conv_w8_patch_kernel_shapes(N, B, C, H, W, Co, k, s, p, xdt):
 @pytest.mark.parametrize("xdt", ["f32", "bf16"])
 def test_conv_w8_patch_kernel_bf16_out_no_bias(N, xdt):
     check(N, 6, 64, 20, 20, 72, 3, 1, 1, xdt, seed=5, bias=False, out_dtype=torch.bfloat16, beta=0.5)
+    check(N, 40, 64, 7, 7, 72, 3, 1, 1, xdt, seed=6, bias=False, out_dtype=torch.bfloat16, beta=0.5)
 
 
 def test_conv_w8_patch_kernel_integer_activations_are_exact(N):
