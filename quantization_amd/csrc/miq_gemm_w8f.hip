@@ -1512,6 +1512,273 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
 #undef MIQ_PATCH_RUN
 }
 
+// ---------------------------------------------------------------------------------------
+// Stems: at most four input channels, five to eight filter columns, at most seven filter rows, stride 2 (ResNet's
+// 3 -> 64 7 x 7 / 2).  In im2col order such a layer's K axis is mostly padding (KH rows of 64 elements, of which
+// KW * Cin are real) and every activation is staged a dozen times; the tile kernel took 940 us (fp32) / 640 us (bf16) for
+// ResNet-18's first layer at batch 256, a quarter of the whole stack.  Here (the int8 convolution's conv_stem_kernel,
+// miq_conv2d_i8.hip, carried over) the padded copy is PIXEL-major, one 16-byte pixel of eight virtual channels:
+// (c0 c1 c2 c3 | 0 0 0 0) for bf16 activations, (hi c0..c3 | lo c0..c3) for fp32 / fp16; a workgroup of eight waves owns
+// 8 output rows x 64 pixels x 64 channels, stages the patch those pixels see once (14 + KH rows of 136 pixels) and the
+// channel tile's filters once per workgroup, and the im2col expansion happens between LDS and registers: K-step
+// j = 2 * kh + half of output pixel (y, x) is the four pixels (2y + kh, 2x + 4 * half + q), q = lane >> 4, one 16-byte
+// read per lane.  The filters are widened to bf16 by the re-layout: [K-step][q][channel][8], the hi and the lo half of a
+// pixel meeting the same four weights.  Wave w multiplies output row w (four fragments of 16 pixels) by all 64 channels;
+// the activation fragment is the MFMA's first operand, so a lane ends with four consecutive pixels of one channel.
+// ---------------------------------------------------------------------------------------
+constexpr int kStemW8Pitch = 136;                         // patch pixels per row: 63 * 2 + 8 = 134, rounded up
+constexpr int kStemW8PatchBytes = 21 * kStemW8Pitch * kChunk + 512;   // 14 + KH <= 21 rows, fetched as 45 wave-instructions
+constexpr int kStemW8MaxSteps = 14;                       // 2 * KH
+constexpr int kStemW8WeightBytes = kStemW8MaxSteps * 4 * 64 * kChunk;
+
+struct StemW8Args {
+    const void* xp;       // [b][hp][wp][8 bf16]
+    const void* wp;       // [Cout / 64][K-step][q][64][8 bf16]
+    const float* bias;
+    const float* alpha;
+    void* out;
+    float beta;
+    int Cout, KH, ksteps;
+    int Hp, Wp, Ho, Wo;
+    int tiles_x, tiles_y, tiles_n, units;
+    uint32_t xp_bytes, wp_bytes;
+};
+
+// NCHW activation (Cin <= 4) -> padded pixel-major copy, and OIHW int8 filters -> the kernel's weight image, in one launch:
+// workgroups [0, n_prep) take one padded pixel per thread, the rest one 16-byte weight chunk per thread.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void stem_w8_prep_kernel(const T* __restrict__ x, uint4* __restrict__ xp, int Cin, int H, int W,
+                                                           int Hp, int Wp, int pad, uint32_t npix, int n_prep,
+                                                           const int8_t* __restrict__ w, uint4* __restrict__ wp, uint32_t wchunks,
+                                                           int Cout, int KH, int KW) {
+    if (static_cast<int>(blockIdx.x) < n_prep) {
+        for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < npix; idx += 256u * n_prep) {
+            const uint32_t rowi = idx / Wp, s = idx - rowi * Wp, b = rowi / Hp, hp = rowi - b * Hp;
+            const int h = static_cast<int>(hp) - pad, ww = static_cast<int>(s) - pad;
+            float fh[4] = {0.f, 0.f, 0.f, 0.f}, fl[4] = {0.f, 0.f, 0.f, 0.f};
+            if (h >= 0 && h < H && ww >= 0 && ww < W) {
+                const T* src = x + (static_cast<size_t>(b) * Cin * H + h) * W + ww;
+                const size_t cs = static_cast<size_t>(H) * W;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= Cin) break;
+                    const float v = to_f32(src[c * cs]);
+                    fh[c] = bf16_round(v);
+                    if constexpr (NP == 2) {
+                        if (__builtin_isinf(fh[c]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
+                            fh[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+                        fl[c] = (__builtin_isinf(fh[c]) || fh[c] != fh[c]) ? 0.0f : __fsub_rn(v, fh[c]);
+                    }
+                }
+            }
+            xp[idx] = uint4{pack2_bf16(fh[0], fh[1]), pack2_bf16(fh[2], fh[3]), pack2_bf16(fl[0], fl[1]), pack2_bf16(fl[2], fl[3])};
+        }
+        return;
+    }
+    const int n_pack = static_cast<int>(gridDim.x) - n_prep;
+    for (uint32_t idx = (blockIdx.x - n_prep) * 256u + threadIdx.x; idx < wchunks; idx += 256u * n_pack) {
+        const uint32_t nl = idx & 63, q = (idx >> 6) & 3;
+        const uint32_t rest = idx >> 8, j = rest % (2 * KH), tn = rest / (2 * KH);
+        const uint32_t kh = j >> 1, kw = 4 * (j & 1) + q, n = tn * 64 + nl;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < static_cast<uint32_t>(Cout) && kw < static_cast<uint32_t>(KW)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < Cin) v[c] = static_cast<float>(w[((static_cast<size_t>(n) * Cin + c) * KH + kh) * KW + kw]);
+        }
+        const uint32_t lo = pack2_bf16(v[0], v[1]), hi = pack2_bf16(v[2], v[3]);
+        wp[idx] = NP == 2 ? uint4{lo, hi, lo, hi} : uint4{lo, hi, 0u, 0u};
+    }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(512, 2) void conv_stem_w8_kernel(StemW8Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, the channel tile's filters
+    char* const wst = smem + 2 * kStemW8PatchBytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int tn = static_cast<int>(blockIdx.x) % g.tiles_n;   // the grid is a multiple of tiles_n: one channel tile per workgroup
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
+    struct Block {
+        int x0, y0;
+        uint32_t b;
+    };
+    auto decode = [&](uint32_t unit) {
+        Block k;
+        uint32_t t = unit / g.tiles_n;
+        k.x0 = (t % g.tiles_x) * 64;
+        t /= g.tiles_x;
+        k.y0 = (t % g.tiles_y) * 8;
+        k.b = t / g.tiles_y;
+        return k;
+    };
+    // patch: rows 2*y0 .. 2*y0 + 13 + KH of the padded image, 136 pixels from pixel 2*x0 (a run that leaves the row continues
+    // into the next one, one that leaves the buffer reads zeros: both only under pixels that are never stored)
+    const int pieces = (14 + g.KH) * kStemW8Pitch;
+    auto fetch_patch = [&](const Block& k, char* patch) {
+        for (int i = wave; i * 64 < pieces; i += 8) {
+            const int id = i * 64 + lane, row = id / kStemW8Pitch, px = id - row * kStemW8Pitch;
+            const uint32_t off = id < pieces ? ((k.b * g.Hp + k.y0 * 2 + row) * g.Wp + k.x0 * 2 + px) * kChunk : kOob;
+            dma16(rx, patch + i * 1024, off);
+        }
+    };
+    // filters of the channel tile: 4 wave-instructions a K-step, as they lie
+    for (int c = wave; c < g.ksteps * 4; c += 8)
+        dma16(rw, wst + c * 1024, (static_cast<uint32_t>(tn) * g.ksteps * 4 + c) * 1024 + lane * kChunk);
+    // this lane's channel of each 16-channel fragment: epilogue parameters, once per workgroup
+    float al[4], bi[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int n = tn * 64 + f * 16 + r;
+        al[f] = 1.f;
+        bi[f] = 0.f;
+        if (n < g.Cout) {
+            al[f] = g.alpha[n];
+            if (g.bias) bi[f] = g.bias[n];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the counted waits below count from here)
+
+    uint32_t unit = blockIdx.x;
+    const uint32_t units = static_cast<uint32_t>(g.units);
+    Block cur = decode(unit);
+    fetch_patch(cur, smem);
+    const char* w_lane = wst + (q * 64 + r) * kChunk;
+    // this lane's patch offset for fragment 0 and K-step 0: output row `wave`, output column r, pixel q of the step's four
+    const int a_off = ((wave * 2) * kStemW8Pitch + r * 2 + q) * kChunk;
+    const int HoWo = g.Ho * g.Wo;
+    constexpr int kEsz = OUT == kOutBF16 ? 2 : 4;
+    int buf = 0;
+    int stores = 0;   // store instructions this wave issued behind the fetch of the patch about to be read
+    for (; unit < units; unit += gridDim.x) {
+        // Vector memory operations retire in issue order: once all but the stores issued after it are done, this wave's
+        // pieces of the patch have landed, and the stores go on draining under the next block's arithmetic.
+        wait_vmcnt_upto16(stores);
+        __syncthreads();   // every wave's pieces have landed; every wave has left the buffer the next fetch overwrites
+        {
+            // store instructions certain to issue (their lane 0 stores): fragments that start inside the row x channel
+            // groups that start inside Cout, if the wave's row is inside the image
+            const int fx = min(4, max(0, (g.Wo - cur.x0 + 15) >> 4)), fc = min(4, max(0, (g.Cout - tn * 64 + 15) >> 4));
+            stores = cur.y0 + wave < g.Ho ? fx * fc : 0;
+        }
+        const uint32_t nunit = unit + gridDim.x;
+        const Block nxt = decode(nunit < units ? nunit : unit);
+        if (nunit < units) fetch_patch(nxt, smem + (buf ^ 1) * kStemW8PatchBytes);
+
+        v4f acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = v4f{0.f, 0.f, 0.f, 0.f};
+        const char* a_lane = smem + buf * kStemW8PatchBytes + a_off;
+        for (int j = 0; j < g.ksteps; ++j) {
+            v8bf af[4], wf[4];
+            const char* a = a_lane + ((j >> 1) * kStemW8Pitch + (j & 1) * 4) * kChunk;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = __builtin_bit_cast(v8bf, lds_read16(w_lane + j * 4096 + f * 256));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(v8bf, lds_read16(a + i * 32 * kChunk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[f], acc[i][f], 0, 0, 0);
+        }
+
+        // D[R][c] of fragment (i, f): R = 4*(lane>>4) + reg -> pixel i*16 + R of the wave's row, c = lane&15 -> channel f*16 + c
+        const int y = cur.y0 + wave;
+        if (y < g.Ho) {
+            const int xq = cur.x0 + q * 4;   // this lane's first pixel of fragment 0
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int n = tn * 64 + f * 16 + r;
+                if (n >= g.Cout) continue;
+                char* const row = static_cast<char*>(g.out) +
+                                  ((static_cast<size_t>(cur.b) * g.Cout + n) * HoWo + static_cast<size_t>(y) * g.Wo + xq) * kEsz;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (xq + i * 16 >= g.Wo) continue;
+                    const v4f a = acc[i][f];
+                    const float y0 = dequant1f(a[0], bi[f], al[f], g.beta), y1 = dequant1f(a[1], bi[f], al[f], g.beta);
+                    const float y2 = dequant1f(a[2], bi[f], al[f], g.beta), y3 = dequant1f(a[3], bi[f], al[f], g.beta);
+                    if constexpr (OUT == kOutF32) {
+                        __builtin_nontemporal_store(v4f{y0, y1, y2, y3}, reinterpret_cast<v4f*>(row + i * 16 * kEsz));
+                    } else {
+                        const uint2 h = pack4_bf16(y0, y1, y2, y3);
+                        *reinterpret_cast<uint2*>(row + i * 16 * kEsz) = h;
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        buf ^= 1;
+    }
+}
+
+// Whether a layer takes the stem kernel, and its workspace: the pixel-major copy (rounded up to 256 bytes) + the filters.
+struct StemW8Geom {
+    bool ok;
+    int64_t Hp, Wp, Ho, Wo, xp_bytes, wp_bytes;
+};
+
+StemW8Geom make_stem_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t stride,
+                             int64_t pad) {
+    StemW8Geom p{};
+    const char* sw = dev_switch("MIQ_CONV_W8_STEM");   // developer A/B switch: 0 = tile kernel
+    if (Cin > 4 || KW < 5 || KW > 8 || KH > 7 || stride != 2 || Cout <= 0 || (sw && sw[0] == '0')) return p;
+    p.Hp = H + 2 * pad;
+    p.Wp = W + 2 * pad;
+    if (p.Hp < KH || p.Wp < KW) return p;
+    p.Ho = (p.Hp - KH) / 2 + 1;
+    p.Wo = (p.Wp - KW) / 2 + 1;
+    if (p.Wo % 4 != 0 || B * p.Ho * p.Wo < 1024) return p;
+    p.xp_bytes = B * p.Hp * p.Wp * kChunk;
+    p.wp_bytes = ceil_div(Cout, 64) * 2 * KH * 4 * 64 * kChunk;
+    if (p.xp_bytes >= (1ll << 31) || B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 64) * ceil_div(Cout, 64) >= (1ll << 31)) return p;
+    p.ok = true;
+    return p;
+}
+
+int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                int64_t Cout, int64_t KH, int64_t KW, int64_t pad, const float* bias, const float* alpha, float beta, void* out,
+                int out_dtype, void* workspace, hipStream_t st) {
+    uint4* xp = static_cast<uint4*>(workspace);
+    uint4* wp = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
+    const uint32_t npix = static_cast<uint32_t>(P.xp_bytes / kChunk), wchunks = static_cast<uint32_t>(P.wp_bytes / kChunk);
+    const int n_prep = static_cast<int>(std::min<int64_t>(ceil_div(npix, 256), 1 << 20));
+    const int n_pack = static_cast<int>(std::min<int64_t>(ceil_div(wchunks, 256), 4096));
+#define MIQ_STEM_PREP(T, NP)                                                                                               \
+    stem_w8_prep_kernel<T, NP><<<n_prep + n_pack, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp, \
+                                                                (int)P.Wp, (int)pad, npix, n_prep, w, wp, wchunks, (int)Cout, \
+                                                                (int)KH, (int)KW)
+    if (x_dtype == MIQ_F32)
+        MIQ_STEM_PREP(float, 2);
+    else if (x_dtype == MIQ_F16)
+        MIQ_STEM_PREP(_Float16, 2);
+    else
+        MIQ_STEM_PREP(__bf16, 1);
+#undef MIQ_STEM_PREP
+    if (int rc = check_launch("stem_w8_prep_kernel")) return rc;
+
+    StemW8Args a{};
+    a.xp = xp; a.wp = wp; a.bias = bias; a.alpha = alpha; a.out = out; a.beta = beta;
+    a.Cout = (int)Cout; a.KH = (int)KH; a.ksteps = (int)(2 * KH);
+    a.Hp = (int)P.Hp; a.Wp = (int)P.Wp; a.Ho = (int)P.Ho; a.Wo = (int)P.Wo;
+    a.tiles_x = (int)ceil_div(P.Wo, 64); a.tiles_y = (int)ceil_div(P.Ho, 8); a.tiles_n = (int)ceil_div(Cout, 64);
+    a.units = (int)(B * a.tiles_y * a.tiles_x * a.tiles_n);
+    a.xp_bytes = (uint32_t)P.xp_bytes; a.wp_bytes = (uint32_t)P.wp_bytes;
+    constexpr int kLds = 2 * kStemW8PatchBytes + kStemW8WeightBytes;
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
+    void (*kern)(StemW8Args) = out_dtype == MIQ_F32 ? conv_stem_w8_kernel<kOutF32> : conv_stem_w8_kernel<kOutBF16>;
+    if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
+    int grid = a.units < 256 ? a.units : 256 - 256 % a.tiles_n;   // one persistent workgroup per CU, each keeping one channel tile
+    if (grid < a.tiles_n) grid = a.units < a.tiles_n ? a.units : a.tiles_n;
+    kern<<<grid, 512, kLds, st>>>(a);
+    return check_launch("conv_stem_w8_kernel");
+}
+
 }  // namespace
 
 extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
@@ -1602,6 +1869,8 @@ extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, i
     if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
     const PatchW8Geom P = make_patch_w8_geom(x_dtype == MIQ_BF16 ? 1 : 2, B, Cin, H, W, Cout, KH, KW, stride, pad);
     if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256) + round_up(P.wp_bytes, 256));
+    const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    if (S.ok) return static_cast<size_t>(round_up(S.xp_bytes, 256) + round_up(S.wp_bytes, 256));
     return static_cast<size_t>((x_dtype == MIQ_BF16 ? 1 : 2) * G.plane_bytes + G.wp_bytes);
 }
 
@@ -1640,6 +1909,14 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
             MIQ_REQUIRE((P.Ho * P.Wo) % 4 != 0 || miq::aligned(out, 4 * esz), MIQ_EALIGN,
                         "miq_conv2d_w8: out must be aligned to four of its elements");
             return run_patch_w8(P, x, x_dtype, w, B, Cin, H, W, Cout, pad, bias, alpha, beta, out, out_dtype, workspace, st);
+        }
+    }
+    // stems (at most four input channels, 5-8 filter columns, stride 2) whose output rows are whole 16-byte vectors
+    {
+        const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
+        if (S.ok) {
+            MIQ_REQUIRE(miq::aligned(out, 4 * esz), MIQ_EALIGN, "miq_conv2d_w8: out must be aligned to four of its elements");
+            return run_stem_w8(S, x, x_dtype, w, B, Cin, H, W, Cout, KH, KW, pad, bias, alpha, beta, out, out_dtype, workspace, st);
         }
     }
     H = G.H; W = G.W; stride = G.stride;   // a subsampled 1 x 1 layer continues as its stride-1 equivalent

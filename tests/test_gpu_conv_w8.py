@@ -119,6 +119,34 @@ def test_conv_w8_patch_kernel_integer_activations_are_exact(N):
         np.testing.assert_array_equal(y.cpu().numpy(), ref)
 
 
+# stems (Cin <= 4, 5-7 filter rows and columns, stride 2, output rows of whole 16-byte vectors): ragged row and pixel blocks,
+# ragged channel tiles, two pixel blocks a row, one to four input channels
+STEM_CASES = [
+    (4, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (3, 2, 33, 48, 130, 5, 2, 2), (2, 4, 64, 64, 64, 7, 2, 3),
+    (1, 3, 30, 224, 64, 7, 2, 3), (3, 1, 40, 40, 16, 6, 2, 2),
+]
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p", STEM_CASES)
+def test_conv_w8_stem_kernel_shapes(N, B, C, H, W, Co, k, s, p, xdt):
+    check(N, B, C, H, W, Co, k, s, p, xdt, seed=B * 11 + C + Co)
+
+
+def test_conv_w8_stem_kernel_bf16_out_and_exact_integers(N):
+    check(N, 3, 3, 45, 40, 80, 7, 2, 3, "f32", seed=8, bias=False, out_dtype=torch.bfloat16, beta=0.5)
+    from oracle import oracle_c as OC
+    g = torch.Generator().manual_seed(22)
+    x = torch.randint(-8, 9, (3, 3, 40, 48), generator=g).float()
+    w = torch.randint(-128, 128, (70, 3, 7, 7), generator=g, dtype=torch.int32).to(torch.int8)
+    alpha, bias = torch.rand(70, generator=g) * 0.02 + 1e-4, torch.randn(70, generator=g) * 5
+    acc = F.conv2d(x.double(), w.double(), stride=2, padding=3).to(torch.int32).numpy()
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), 0.25)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        y = N.conv2d_w8(x.to(dt).cuda(), w.cuda(), 2, 3, bias=bias.cuda(), alpha=alpha.cuda(), beta=0.25)
+        np.testing.assert_array_equal(y.cpu().numpy(), ref)
+
+
 def test_conv_w8_1x1_strided_random_shapes(N):
     """Seeded random 1 x 1 layers with stride 2..4 (the subsampling re-layout) on all three activation types."""
     rng = np.random.default_rng(78)
