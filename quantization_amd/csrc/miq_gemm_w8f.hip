@@ -1075,8 +1075,8 @@ size_t w8f_slab_bytes(int64_t M, int64_t N, int64_t K, int planes) {
 //     planes 4g + {0, 1} = hi of channels 16g .. +7 / +8 .. +15, planes 4g + {2, 3} = lo of the same, and the weight
 //     fragment of k-group q is that of q & 1, so one MFMA sums (hi + lo) * w over sixteen channels.
 // The filters of a group sit beside the patch as [tap][k-group][output channel][8 bf16], widened from int8 (exactly) by
-// the filter re-layout, so a tap carries no conversion (widening in registers, as the GEMM kernels do, cost the taps
-// 40 vector instructions beside 14 MFMAs: 203 -> see profiles).  Everything else is the int8 kernel's structure: one persistent workgroup per CU (eight waves, 256
+// the filter re-layout, so a tap carries no conversion (widened in registers, as the GEMM kernels do, a tap carried 40
+// vector instructions beside its 14 MFMAs).  Everything else is the int8 kernel's structure: one persistent workgroup per CU (eight waves, 256
 // registers, two LDS stages), the next stage fetched piece by piece among the nine taps, tap t + 1's fragments read under
 // tap t's MFMAs, a finished unit's accumulators handed to a second register set and stored one fragment row per tap of
 // the next unit, one barrier per stage; small images take several whole images per tile.
