@@ -218,6 +218,31 @@ int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin
                        int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias, const float* alpha,
                        float beta, void* out, int out_dtype, int64_t out_pad, void* stream);
 
+/* Conv2d with every argument nn.Conv2d has: a stride, a dilation and a padding per axis, groups, and a padding that may
+ * differ before and after (padding='same' on an even filter extent).  NCHW activations of x_dtype MIQ_I8 | MIQ_F32 |
+ * MIQ_F16 | MIQ_BF16, int8 weights [Cout][Cin / groups][KH][KW], NCHW output:
+ *     out[b,o,y,x] = (sum_{c,i,j} x[b, g(o)*Cin/groups + c, y*stride_h + i*dil_h - pad_top, x*stride_w + j*dil_w - pad_left]
+ *                     * w[o,c,i,j] + bias[o]) * alpha[o] + beta          (positions outside the image count as 0)
+ *     Ho = (H + pad_top + pad_bottom - dil_h*(KH-1) - 1) / stride_h + 1, Wo likewise.
+ * Replaces F.conv2d(x, weight.to(x.dtype), stride, padding, dilation, groups) + bias + Qop.dequantize in the layers'
+ * forward (quant/Weight_Only/Quantizer.py:73-86, quant/Weight_Activation/Quantizer.py:53-60) for the layers that
+ * miq_conv2d_i8 / miq_conv2d_w8 (dilation 1, groups 1, one stride and padding: all that conv2d_int8 of
+ * cuda_kernels/conv2d_int8/conv2d_w8a8.cu:81-114 knows) do not take.  Dense layers (groups = 1) run on the same
+ * implicit-GEMM MFMA kernels as those two, with the arithmetic of miq_conv2d_i8 (exact int32) / miq_conv2d_w8 (bf16
+ * planes, fp32 accumulation); grouped and depthwise layers on a direct convolution on the vector ALUs (int32, or fp32
+ * fused multiply-adds).
+ * out_dtype MIQ_F32 | MIQ_BF16, or MIQ_I32 (raw sums, int8 activations only; bias / alpha unused).
+ * workspace: at least miq_conv2d_general_workspace(...) bytes, 256-byte aligned (the padded channels-last copy of x and
+ * the re-laid weight of a dense layer); 0 bytes, and then NULL will do, for grouped layers. */
+size_t miq_conv2d_general_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                                    int64_t KW, int64_t stride_h, int64_t stride_w, int64_t pad_top, int64_t pad_bottom,
+                                    int64_t pad_left, int64_t pad_right, int64_t dil_h, int64_t dil_w, int64_t groups);
+int miq_conv2d_general(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                       int64_t Cout, int64_t KH, int64_t KW, int64_t stride_h, int64_t stride_w, int64_t pad_top,
+                       int64_t pad_bottom, int64_t pad_left, int64_t pad_right, int64_t dil_h, int64_t dil_w,
+                       int64_t groups, const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* 2-D pooling with an int8 result, NCHW: what QuantizedMaxPool2d / QuantizedAvgPool2d compute
  * (quant/Weight_Activation/Quantizer.py:122-130: nn.MaxPool2d / nn.AvgPool2d on x.float(), then
  * .to(torch.int8)), in one pass over x.

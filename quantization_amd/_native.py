@@ -50,6 +50,8 @@ SYMBOLS = {
     "miq_conv2d_i8_packed_weight_bytes": (_size, [_i64] * 4),
     "miq_conv2d_i8_pack_weight": (_int, [_p] + [_i64] * 4 + [_p, _p]),
     "miq_conv2d_i8_nhwc": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _i64, _p]),
+    "miq_conv2d_general_workspace": (_size, [_int] + [_i64] * 16),
+    "miq_conv2d_general": (_int, [_p, _int, _p] + [_i64] * 16 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_pool2d_to_i8": (_int, [_p, _int] + [_i64] * 4 + [_int] * 7 + [_p, _p]),
     "miq_tensor_minmax_workspace": (_size, [_i64]),
     "miq_tensor_minmax": (_int, [_p, _int, _i64, _p, _p, _size, _p]),
@@ -477,6 +479,84 @@ def conv2d_i8_nhwc(x, wp, kernel_shape, stride=1, padding=0, bias=None, alpha=No
     with _on(x.device):
         _check(lib().miq_conv2d_i8_nhwc(_ptr(x), _ptr(wp), B, Ci, H, W, Co, KH, KW, stride, padding, _ptr(bias), _ptr(alpha),
                                         float(beta), _ptr(out), _OUT_CODES_CL[out_dtype], out_pad, _stream()))
+    return out
+
+
+def _pair(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) == 1:
+            return int(v[0]), int(v[0])
+        if len(v) != 2:
+            raise RuntimeError(f"expected one or two values, got {v!r}")
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+def conv_padding(padding, KH, KW, stride=1, dilation=1):
+    """(top, bottom, left, right) zero rows / columns for nn.Conv2d's `padding` argument: an integer, a pair, 'valid', or
+    'same' (as F.conv2d: dil * (k - 1) in total per axis, the odd one behind; stride 1 only)."""
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    if isinstance(padding, str):
+        if padding == "valid":
+            return 0, 0, 0, 0
+        if padding == "same":
+            if sh != 1 or sw != 1:
+                raise RuntimeError("padding='same' is not supported for strided convolutions")
+            th, tw = dh * (KH - 1), dw * (KW - 1)
+            return th // 2, th - th // 2, tw // 2, tw - tw // 2
+        raise RuntimeError(f"unknown padding mode {padding!r}")
+    pt, pl = _pair(padding)
+    if pt < 0 or pl < 0:
+        raise RuntimeError(f"bad padding {padding}")
+    return pt, pt, pl, pl
+
+
+def conv2d_general(x, w, stride=1, padding=0, dilation=1, groups=1, bias=None, alpha=None, beta=0.0,
+                   out_dtype=torch.float32, out=None):
+    """Conv2d with nn.Conv2d's full argument set (a stride / dilation / padding per axis, groups, padding 'valid' or
+    'same'): NCHW x (int8, fp32, fp16 or bf16), int8 w [Cout, Cin / groups, KH, KW], per-channel (acc + bias) * alpha + beta
+    (out_dtype int32, int8 x only: the raw sums)."""
+    require_device(x, "input")
+    require_device(w, "kernel")
+    codes = {**_FLOAT_CODES, torch.int8: MIQ_I8}
+    if x.dtype not in codes or w.dtype != torch.int8:
+        raise RuntimeError(f"input must be int8/fp32/fp16/bf16 and kernel int8 (got {x.dtype}, {w.dtype})")
+    if x.dim() != 4 or w.dim() != 4:
+        raise RuntimeError("input and kernel must be 4-D (NCHW / OIHW)")
+    groups = int(groups)
+    B, C, H, W = x.shape
+    Co, Cg, KH, KW = w.shape
+    if groups < 1 or C % groups or Co % groups or Cg != C // groups:
+        raise RuntimeError(f"shape mismatch: input {tuple(x.shape)}, kernel {tuple(w.shape)}, groups {groups}")
+    if out_dtype not in _OUT_CODES or (out_dtype == torch.int32 and x.dtype != torch.int8):
+        raise RuntimeError(f"unsupported output dtype {out_dtype} for {x.dtype} input")
+    if out_dtype != torch.int32 and alpha is None:
+        raise RuntimeError("alpha (the per-channel scale) is required")
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
+    if sh < 1 or sw < 1 or dh < 1 or dw < 1:
+        raise RuntimeError(f"bad stride / dilation ({stride}, {dilation})")
+    pt, pb, pl, pr = conv_padding(padding, KH, KW, (sh, sw), (dh, dw))
+    eh, ew = dh * (KH - 1) + 1, dw * (KW - 1) + 1
+    if H + pt + pb < eh or W + pl + pr < ew:
+        raise RuntimeError("kernel larger than the padded input")
+    Ho, Wo = (H + pt + pb - eh) // sh + 1, (W + pl + pr - ew) // sw + 1
+    bias = _f32_vec(bias, Co, "bias", x.device)
+    alpha = _f32_vec(alpha, Co, "alpha", x.device)
+    if out is None:
+        out = torch.empty((B, Co, Ho, Wo), dtype=out_dtype, device=x.device)
+    else:
+        require_device(out, "out")
+        if tuple(out.shape) != (B, Co, Ho, Wo) or out.dtype != out_dtype or out.device != x.device:
+            raise RuntimeError("out has the wrong shape, dtype or device")
+    L = lib()
+    need = L.miq_conv2d_general_workspace(codes[x.dtype], B, C, H, W, Co, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, groups)
+    ws = torch.empty(need, dtype=torch.int8, device=x.device) if need else None
+    with _on(x.device):
+        _check(L.miq_conv2d_general(_ptr(x), codes[x.dtype], _ptr(w), B, C, H, W, Co, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw,
+                                    groups, _ptr(bias), _ptr(alpha), float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws),
+                                    need, _stream()))
     return out
 
 

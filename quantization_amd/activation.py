@@ -78,20 +78,29 @@ def linear_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, out_dtype=torc
 
 
 @torch.no_grad()
-def conv2d_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, stride=1, padding=0, out_dtype=torch.float32):
-    """Weight-only quantized Conv2d (dilation 1, groups 1) on a float activation x [B, Cin, H, W], through the
-    int8 convolution: x is quantized per tensor on the fly into a frame filled with its zero point, and the
-    zero-point correction, both scales and the bias ride the fused epilogue.  Nothing on the host."""
+def conv2d_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, stride=1, padding=0, out_dtype=torch.float32,
+                        dilation=1, groups=1):
+    """Weight-only quantized Conv2d on a float activation x [B, Cin, H, W], through the int8 convolution: x is
+    quantized per tensor on the fly into a frame filled with its zero point, and the zero-point correction, both
+    scales and the bias ride the fused epilogue.  Nothing on the host.  stride / padding / dilation / groups as
+    nn.Conv2d takes them; anything but one stride, one numeric padding, dilation 1 and groups 1 runs on the direct
+    convolution kernel."""
     _native.require_device(x, "input")
     x = x.contiguous()
     B, C, H, W = x.shape
     if w_rowsum is None:
         w_rowsum = weight_rowsum(wq)
+    pt, pb, pl, pr = _native.conv_padding(padding, wq.shape[2], wq.shape[3], stride, dilation)
     scale_zp, alpha, corr = _native.dynamic_epilogue_i8(_native.tensor_minmax(x), w_scale.reshape(-1), bias, w_rowsum)
     xq = _native.quantize_rows_given_i8(x.view(B * C, H * W), scale_zp[0:1], scale_zp[1:2]).view(B, C, H, W)
-    if padding:
-        framed = torch.empty((B, C, H + 2 * padding, W + 2 * padding), dtype=torch.int8, device=x.device)
+    if pt or pb or pl or pr:
+        framed = torch.empty((B, C, H + pt + pb, W + pl + pr), dtype=torch.int8, device=x.device)
         framed.copy_(scale_zp[1].to(torch.int8))          # the zero point is integral and within [-128, 127]
-        framed[:, :, padding:padding + H, padding:padding + W].copy_(xq)
+        framed[:, :, pt:pt + H, pl:pl + W].copy_(xq)
         xq = framed
-    return _native.conv2d_i8(xq, wq, stride, 0, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
+    sh, sw = _native._pair(stride)
+    dh, dw = _native._pair(dilation)
+    if sh == sw and dh == dw == 1 and groups == 1:
+        return _native.conv2d_i8(xq, wq, sh, 0, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
+    return _native.conv2d_general(xq, wq, (sh, sw), 0, (dh, dw), groups, bias=corr, alpha=alpha, beta=0.0,
+                                  out_dtype=out_dtype)

@@ -19,8 +19,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmiq.so")
 DEV_LIB = os.path.join(HERE, "libmiq_dev.so")
-SOURCES = ["miq_api.hip", "miq_quantize.hip", "miq_gemm_i8.hip", "miq_gemm_w8f.hip", "miq_conv2d_i8.hip", "miq_pool.hip", "miq_activation.hip"]
-HEADERS = ["miq_common.h", "miq_gemm_core.h", "miq_patch.h"]
+SOURCES = ["miq_api.hip", "miq_quantize.hip", "miq_gemm_i8.hip", "miq_gemm_w8f.hip", "miq_conv2d_i8.hip", "miq_conv2d_general.hip", "miq_pool.hip", "miq_activation.hip"]
+HEADERS = ["miq_common.h", "miq_gemm_core.h", "miq_patch.h", "miq_conv_dense.h"]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

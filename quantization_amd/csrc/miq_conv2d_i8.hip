@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "miq_common.h"
+#include "miq_conv_dense.h"
 #include "miq_gemm_core.h"
 #include "miq_patch.h"
 
@@ -389,6 +390,10 @@ struct ConvArgs {
     int sx;                   // stride*Cp: bytes between horizontally adjacent output pixels' windows
     int sy;                   // stride*Wp*Cp
     int cps;                  // 16-byte chunks per filter row (Lp / 16)
+    // A dilation along x (miq::conv2d_i8_dense): every filter tap is a "row" of its own, Cp bytes of one pixel; row t
+    // then starts (t / kwt) * row_stride + (t % kwt) * tap_stride bytes into the window.  kwt = 0: rows are filter rows.
+    int kwt, tap_stride;
+    uint32_t kwt_magic;       // floor(2^32 / kwt) + 1
     uint32_t cps_magic;       // floor(2^32 / cps) + 1: q / cps == umulhi(q, cps_magic) for q < 2^16, cps > 1
     uint32_t xp_bytes, wp_bytes;
     int stream_out;           // 1: nontemporal 16-byte output stores (outputs far larger than the 256 MiB cache)
@@ -397,6 +402,13 @@ struct ConvArgs {
     // channels-last output (CL kernels): element strides of out[b][y + border][x + border][channel]
     int o_img, o_row, o_pix, o_off;
 };
+
+// Byte offset of "row" t of a window's K axis (a filter row, or a single tap under a dilation along x).
+__device__ __forceinline__ uint32_t row_offset(const ConvArgs& g, int t) {
+    if (g.kwt == 0) return static_cast<uint32_t>(t * g.row_stride);
+    const int kh = static_cast<int>(__umulhi(static_cast<uint32_t>(t), g.kwt_magic));
+    return static_cast<uint32_t>(kh * g.row_stride + (t - kh * g.kwt) * g.tap_stride);
+}
 
 // Channels-last epilogue shared by the CL kernels: a lane holds four consecutive channels n .. n+3 (n % 4 == 0,
 // Cout % 4 == 0) of output pixel m and stores them as one vector of the output type.
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
             // chunk q of the K axis = filter row q / cps, byte (q % cps) * 16 of that row's run
             const int kh = g.cps == 1 ? q : static_cast<int>(__umulhi(static_cast<uint32_t>(q), g.cps_magic));
             uint32_t off = kOob;
-            if (q < nchunks && pix[i] != kOob) off = pix[i] + kh * g.row_stride + (q - kh * g.cps) * kChunk;
+            if (q < nchunks && pix[i] != kOob) off = pix[i] + row_offset(g, kh) + (q - kh * g.cps) * kChunk;
             dma16(rx, tile + piece * (8 * kTileK), off);
         }
     };
@@ -732,7 +744,7 @@ __global__ __launch_bounds__(512) void conv_i8_pipe_kernel(ConvArgs g) {
         // chunk q of the K axis = filter row q / cps, byte (q % cps) * 16 of that row's run
         const int q = kt * kChunksPerRow + cslot;
         const int kh = g.cps == 1 ? q : static_cast<int>(__umulhi(static_cast<uint32_t>(q), g.cps_magic));
-        const uint32_t koff = static_cast<uint32_t>(kh * g.row_stride + (q - kh * g.cps) * kChunk);
+        const uint32_t koff = row_offset(g, kh) + static_cast<uint32_t>((q - kh * g.cps) * kChunk);
         const bool ok = q < nchunks;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -2020,6 +2032,138 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             return launch<kOutI32>(a, st);
     }
 }
+
+// ---- dense layers with a stride / padding per axis or a dilation ----------------------------------------
+// The im2col-order kernels above already address a window through byte strides, so these layers ride them as they are:
+//   * the padded channels-last copy gets one border width P = the largest of the four paddings (the re-layout kernels
+//     know a single one) and the windows start (P - pad_top) rows and (P - pad_left) pixels into it: the kernels are
+//     handed the copy from that point on;
+//   * the strides of the two axes go into ConvArgs::sy / sx, a dilation along y into row_stride;
+//   * under a dilation along x a filter row is no longer one run of the copy, so every tap becomes a "row" of its own
+//     (ConvArgs::kwt): Cp bytes of one pixel, padded to 16 in the packed weight as any other row.
+namespace {
+
+struct DenseGeom {
+    int64_t P, Hp, Wp, Cp, rows, kw_run, L, Lp, Kp, Ho, Wo, M, xp_bytes, wp_bytes;
+};
+
+bool make_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t sh, int64_t sw,
+                     int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh, int64_t dw, DenseGeom& g) {
+    if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
+        pt < 0 || pb < 0 || pl < 0 || pr < 0)
+        return false;
+    const int64_t eh = dh * (KH - 1) + 1, ew = dw * (KW - 1) + 1;
+    if (H + pt + pb < eh || W + pl + pr < ew) return false;
+    g.P = std::max(std::max(pt, pb), std::max(pl, pr));
+    g.Hp = H + 2 * g.P;
+    g.Wp = W + 2 * g.P;
+    g.Cp = round_up(Cin, kCinAlign);
+    g.rows = dw == 1 ? KH : KH * KW;
+    g.kw_run = dw == 1 ? KW : 1;        // taps of one "row"
+    g.L = g.kw_run * g.Cp;
+    g.Lp = round_up(g.L, kChunk);
+    g.Kp = g.rows * g.Lp;
+    g.Ho = (H + pt + pb - eh) / sh + 1;
+    g.Wo = (W + pl + pr - ew) / sw + 1;
+    g.M = B * g.Ho * g.Wo;
+    g.xp_bytes = B * g.Hp * g.Wp * g.Cp;
+    g.wp_bytes = Cout * g.Kp;
+    return true;
+}
+
+}  // namespace
+
+namespace miq {
+
+size_t conv2d_i8_dense_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t sh,
+                                 int64_t sw, int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh, int64_t dw) {
+    DenseGeom g;
+    if (!make_dense_geom(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, g) || g.M == 0 || Cout == 0) return 0;
+    // (0 as well for what the kernels' 32-bit offsets do not reach: the caller then takes the direct convolution)
+    if (g.xp_bytes >= (1ll << 31) || g.wp_bytes >= (1ll << 31) || g.M >= (1ll << 31) || B >= 65536 || g.Hp >= 65536 ||
+        H * W >= (1ll << 30) || g.Kp / kChunk > 4096)
+        return 0;
+    return static_cast<size_t>(round_up(g.xp_bytes, 256) + round_up(g.wp_bytes, 256));
+}
+
+// The caller (miq_conv2d_general) has checked pointers, dtypes and alignment of bias / alpha.
+int conv2d_i8_dense(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                    int64_t KW, int64_t sh, int64_t sw, int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh, int64_t dw,
+                    const float* bias, const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                    size_t workspace_bytes, hipStream_t st) {
+    DenseGeom G;
+    MIQ_REQUIRE(make_dense_geom(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, G), MIQ_EINVAL,
+                "miq_conv2d_general: bad geometry");
+    if (G.M == 0 || Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(G.xp_bytes < (1ll << 31) && G.wp_bytes < (1ll << 31) && G.M < (1ll << 31) && B < 65536 && G.Hp < 65536 &&
+                    H * W < (1ll << 30),
+                MIQ_ERANGE, "miq_conv2d_general: padded activations (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)G.xp_bytes, (long long)G.wp_bytes);
+    MIQ_REQUIRE(G.Kp / kChunk <= 4096, MIQ_ERANGE, "miq_conv2d_general: KH*KW*Cin too large (%lld > 65536)", (long long)G.Kp);
+    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    MIQ_REQUIRE(aligned(out, 4 * esz), MIQ_EALIGN, "miq_conv2d_general: out must be 16-byte (8 for bf16) aligned");
+    const size_t need = conv2d_i8_dense_workspace(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE, "miq_conv2d_general: needs %zu bytes of workspace (got %zu)",
+                need, workspace_bytes);
+    MIQ_REQUIRE(aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_general: workspace must be 256-byte aligned");
+    int8_t* xp = static_cast<int8_t*>(workspace);
+    int8_t* wp = xp + round_up(G.xp_bytes, 256);
+
+    // the padded channels-last copy (border P all round) and the packed weight, one launch
+    ConvPrepArgs pa{};
+    pa.x = x; pa.xp = xp; pa.w = w; pa.wp = wp;
+    pa.Cin = (int)Cin; pa.H = (int)H; pa.W = (int)W; pa.Hp = (int)G.Hp; pa.Wp = (int)G.Wp; pa.Cp = (int)G.Cp;
+    pa.pad = (int)G.P; pa.cblocks = static_cast<int>(ceil_div(G.Cp, 64));
+    pa.KH = (int)G.rows; pa.KW = (int)G.kw_run; pa.L = (int)G.L; pa.Lp = (int)G.Lp;   // (OIHW is [Cout][Cin][rows][kw_run] either way)
+    pa.n_interior = static_cast<int>(ceil_div(H * W, 64) * pa.cblocks);
+    pa.border_total = static_cast<uint32_t>(B * (2 * G.P * G.Wp + 2 * G.P * H));
+    pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
+    pa.sub = 1; pa.Ws = (int)W; pa.HWs = (int)(H * W);
+    const int64_t extra = ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
+    pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(extra, B), 1), 4096));
+    dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
+    if ((H * W) % 4 == 0 && aligned(x, 4))
+        conv_prep_kernel<1><<<pgrid, 256, 0, st>>>(pa);
+    else
+        conv_prep_kernel<0><<<pgrid, 256, 0, st>>>(pa);
+    if (int rc = check_launch("conv_prep_kernel")) return rc;
+
+    const int64_t origin = ((G.P - pt) * G.Wp + (G.P - pl)) * G.Cp;   // where the first window starts in the copy
+    ConvArgs a{};
+    a.xp = xp + origin;
+    a.wp = wp;
+    a.bias = bias;
+    a.alpha = alpha;
+    a.out = out;
+    a.beta = beta;
+    a.M = static_cast<int>(G.M);
+    a.Cout = static_cast<int>(Cout);
+    a.Kp = static_cast<int>(G.Kp);
+    a.HoWo = static_cast<int>(G.Ho * G.Wo);
+    a.Wo = static_cast<int>(G.Wo);
+    a.img_stride = static_cast<int>(G.Hp * G.Wp * G.Cp);
+    a.row_stride = static_cast<int>(dh * G.Wp * G.Cp);
+    a.sx = static_cast<int>(sw * G.Cp);
+    a.sy = static_cast<int>(sh * G.Wp * G.Cp);
+    a.cps = static_cast<int>(G.Lp / kChunk);
+    a.cps_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(a.cps)) + 1u;
+    if (dw > 1) {
+        a.kwt = static_cast<int>(KW);
+        a.tap_stride = static_cast<int>(dw * G.Cp);
+        a.kwt_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(KW)) + 1u;
+    }
+    a.xp_bytes = static_cast<uint32_t>(G.xp_bytes - origin);
+    a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
+    a.wide16 = out_dtype == MIQ_BF16 && a.HoWo % 8 == 0 && aligned(out, 16);
+    a.stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16);
+    switch (out_dtype) {
+        case MIQ_F32: return launch<kOutF32>(a, st);
+        case MIQ_BF16: return launch<kOutBF16>(a, st);
+        default: return launch<kOutI32>(a, st);
+    }
+}
+
+}  // namespace miq
 
 // ---- channels-last entry points ---------------------------------------------------------------------
 // The packed weight of the channels-last entry point: the im2col-order form wp[Cout][KH][Lp] and, for 3 x 3 filters over

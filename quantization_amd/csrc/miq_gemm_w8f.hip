@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "miq_common.h"
+#include "miq_conv_dense.h"
 #include "miq_gemm_core.h"
 #include "miq_patch.h"
 
@@ -52,7 +53,21 @@ struct W8fArgs {
     int HoWo, Wo, cstride, Lp, L;
     uint32_t row_bytes, pix_bytes, img_bytes, lp_magic;
     int ldc = 0;        // elements between two output rows (GEMM kernels; = N)
+    // Convolutions with a stride per axis, a dilation or unequal paddings (miq::conv2d_w8_dense); zeros = the plain form.
+    int cstride_x = 0;          // stride along x (0: cstride serves both axes)
+    uint32_t krow_bytes = 0;    // bytes between the runs of two consecutive filter rows (0: row_bytes; dilation along y)
+    uint32_t origin = 0;        // byte offset of the first window in the padded copy (its border may be wider than the padding)
+    int kwt = 0;                // > 0 (dilation along x): every tap is a run of its own, kwt taps per filter row, ...
+    uint32_t kwt_magic = 0, tap_bytes = 0;   // ... tap_bytes apart
 };
+
+// Byte offset of run t of a window's K axis: a filter row, or a single tap under a dilation along x.
+__device__ __forceinline__ uint32_t w8f_run_offset(const W8fArgs& g, uint32_t t) {
+    const uint32_t rb = g.krow_bytes ? g.krow_bytes : g.row_bytes;
+    if (g.kwt == 0) return t * rb;
+    const uint32_t kh = __umulhi(t, g.kwt_magic);
+    return kh * rb + (t - kh * g.kwt) * g.tap_bytes;
+}
 
 __device__ __forceinline__ float bf16_round(float x) { return static_cast<float>(static_cast<__bf16>(x)); }
 
@@ -157,8 +172,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
             const int m = m0 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + j * NWAVES) * 8 + ((threadIdx.x & 63) >> 3);
             if (m < g.M) {
                 const int b = m / g.HoWo, pix = m - b * g.HoWo, ho = pix / g.Wo, wo = pix - ho * g.Wo;
-                pixbase[j] = static_cast<uint32_t>(b) * g.img_bytes + static_cast<uint32_t>(ho * g.cstride) * g.row_bytes +
-                             static_cast<uint32_t>(wo * g.cstride) * g.pix_bytes;
+                pixbase[j] = g.origin + static_cast<uint32_t>(b) * g.img_bytes + static_cast<uint32_t>(ho * g.cstride) * g.row_bytes +
+                             static_cast<uint32_t>(wo * (g.cstride_x ? g.cstride_x : g.cstride)) * g.pix_bytes;
             } else {
                 pixbase[j] = kOob;
             }
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
                 const uint32_t kh = __umulhi(e0, g.lp_magic), inrow = e0 - kh * g.Lp;
                 const uint32_t base = pixbase[i % kRowsPerLane];
                 off = (base != kOob && e0 < static_cast<uint32_t>(g.K) && inrow < static_cast<uint32_t>(g.L))
-                          ? p * g.plane_stride + base + kh * g.row_bytes + inrow * 2u : kOob;
+                          ? p * g.plane_stride + base + w8f_run_offset(g, kh) + inrow * 2u : kOob;
             } else {
                 const uint32_t kbyte = static_cast<uint32_t>(2 * kt + h) * kTileK + c * kChunk;
                 const int row = m0 + r;
@@ -1863,6 +1878,68 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
     return run(g, plan);
 }
 
+// The padded channels-last bf16 planes of x (border `pad` all round) and the packed weight wp[Cout][rows][Lp] ((kw, c)
+// order inside a run of kw_run taps), in one launch where the weight re-layout can ride along.  G.H / G.W / G.sub describe
+// the (possibly subsampled) image; rows x kw_run = the filter's taps.
+static int conv_w8_relayout(const void* x, int x_dtype, const int8_t* w, uint16_t* xp, int8_t* wp, const ConvW8Geom& G, int64_t B,
+                     int64_t Cin, int64_t Cout, int64_t rows, int64_t kw_run, int64_t pad, hipStream_t st) {
+    const int64_t H = G.H, W = G.W;
+    const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2;
+    const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp);
+    const int cblocks = static_cast<int>(ceil_div(G.Cp, 64));
+    const int n_interior = static_cast<int>(ceil_div(H * W, 64) * cblocks);
+    const int n_border = static_cast<int>(ceil_div((2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 8), 256));
+    const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
+    // about four weight bytes per thread, spread over the images
+    const bool pack_along = G.Cp > 16;
+    ConvW8PackArgs pk{w, wp, wtotal, 0, (int)rows, (int)kw_run, (int)G.L, (int)G.Lp};
+    if (pack_along) pk.n_wpack = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(ceil_div(wtotal, 1024), B), 1), 4096));
+    const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border + pk.n_wpack);
+    MIQ_REQUIRE(pblocks < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8: too many re-layout blocks");
+    const int pgrid = static_cast<int>(pblocks);
+    const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
+    const int sgrid = static_cast<int>(sitems / 256 + 1 < 16384 ? sitems / 256 + 1 : 16384);
+    const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
+    // 16- or 8-byte source vectors: whole vectors per channel plane, every plane aligned to them, no subsampling
+    const int64_t plane_b = H * W * static_cast<int64_t>(xsz);
+    const bool vec16 = G.sub == 1 && plane_b % 16 == 0 && miq::aligned(x, 16);
+    const char* v8 = dev_switch("MIQ_CONV_W8_VEC8");   // developer A/B switch: 0 = single elements instead of 8-byte vectors
+    const bool vec8 = G.sub == 1 && plane_b % 8 == 0 && miq::aligned(x, 8) && !(v8 && v8[0] == '0');
+#define MIQ_PREP(T, NP)                                                                                              \
+    do {                                                                                                             \
+        if (G.Cp <= 16)                                                                                              \
+            conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems, \
+                                                                      (int)G.sub, (int)G.Hs, (int)G.Ws);     \
+        else if (vec16)                                                                                              \
+            conv_w8_prep_x_kernel<T, NP, 16><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                    (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                    n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
+        else if (vec8)                                                                                               \
+            conv_w8_prep_x_kernel<T, NP, 8><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                   (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                   n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
+        else                                                                                                         \
+            conv_w8_prep_x_kernel<T, NP, 0><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
+                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
+                                                                       n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws, pk); \
+    } while (0)
+    if (x_dtype == MIQ_F32)
+        MIQ_PREP(float, 2);
+    else if (x_dtype == MIQ_F16)
+        MIQ_PREP(_Float16, 2);
+    else
+        MIQ_PREP(__bf16, 1);
+#undef MIQ_PREP
+    if (int rc = check_launch("conv_w8_prep_x_kernel")) return rc;
+    if (!pack_along) {
+        conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
+            w, wp, wtotal, (int)Cin, (int)rows, (int)kw_run, (int)G.Cp, (int)G.L, (int)G.Lp);
+        if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
+    }
+    return MIQ_OK;
+}
+
 extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvW8Geom G;
@@ -1923,58 +2000,7 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
 
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
-    const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp);
-    const int cblocks = static_cast<int>(ceil_div(G.Cp, 64));
-    const int n_interior = static_cast<int>(ceil_div(H * W, 64) * cblocks);
-    const int n_border = static_cast<int>(ceil_div((2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 8), 256));
-    const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
-    // about four weight bytes per thread, spread over the images
-    const bool pack_along = G.Cp > 16;
-    ConvW8PackArgs pk{w, wp, wtotal, 0, (int)KH, (int)KW, (int)G.L, (int)G.Lp};
-    if (pack_along) pk.n_wpack = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(ceil_div(wtotal, 1024), B), 1), 4096));
-    const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border + pk.n_wpack);
-    MIQ_REQUIRE(pblocks < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8: too many re-layout blocks");
-    const int pgrid = static_cast<int>(pblocks);
-    const uint32_t sitems = npix * static_cast<uint32_t>(G.Cp / 8);
-    const int sgrid = static_cast<int>(sitems / 256 + 1 < 16384 ? sitems / 256 + 1 : 16384);
-    const uint32_t plane_elems = static_cast<uint32_t>(G.plane_bytes / 2);
-    // 16- or 8-byte source vectors: whole vectors per channel plane, every plane aligned to them, no subsampling
-    const int64_t plane_b = H * W * static_cast<int64_t>(xsz);
-    const bool vec16 = G.sub == 1 && plane_b % 16 == 0 && miq::aligned(x, 16);
-    const char* v8 = dev_switch("MIQ_CONV_W8_VEC8");   // developer A/B switch: 0 = single elements instead of 8-byte vectors
-    const bool vec8 = G.sub == 1 && plane_b % 8 == 0 && miq::aligned(x, 8) && !(v8 && v8[0] == '0');
-#define MIQ_PREP(T, NP)                                                                                              \
-    do {                                                                                                             \
-        if (G.Cp <= 16)                                                                                              \
-            conv_w8_prep_x_small_kernel<T, NP><<<sgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                      (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, npix, sitems, \
-                                                                      (int)G.sub, (int)G.Hs, (int)G.Ws);     \
-        else if (vec16)                                                                                              \
-            conv_w8_prep_x_kernel<T, NP, 16><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                    (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                    n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
-        else if (vec8)                                                                                               \
-            conv_w8_prep_x_kernel<T, NP, 8><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                   (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                   n_interior, n_border, 1, (int)G.Hs, (int)G.Ws, pk); \
-        else                                                                                                         \
-            conv_w8_prep_x_kernel<T, NP, 0><<<pgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, plane_elems, (int)Cin, (int)H, \
-                                                                       (int)W, (int)G.Hp, (int)G.Wp, (int)G.Cp, (int)pad, cblocks, \
-                                                                       n_interior, n_border, (int)G.sub, (int)G.Hs, (int)G.Ws, pk); \
-    } while (0)
-    if (x_dtype == MIQ_F32)
-        MIQ_PREP(float, 2);
-    else if (x_dtype == MIQ_F16)
-        MIQ_PREP(_Float16, 2);
-    else
-        MIQ_PREP(__bf16, 1);
-#undef MIQ_PREP
-    if (int rc = check_launch("conv_w8_prep_x_kernel")) return rc;
-    if (!pack_along) {
-        conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
-            w, wp, wtotal, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L, (int)G.Lp);
-        if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
-    }
+    if (int rc = conv_w8_relayout(x, x_dtype, w, xp, wp, G, B, Cin, Cout, KH, KW, pad, st)) return rc;
 
     W8fArgs g{xp, wp, bias, alpha, out, beta, static_cast<int>(G.M), static_cast<int>(Cout), static_cast<int>(G.K),
               static_cast<uint32_t>(G.plane_bytes), 0, 0, 0,
@@ -1985,3 +2011,97 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     if (planes == 2) return out_dtype == MIQ_F32 ? launch_conv_w8f_np<2, kOutF32>(g, st) : launch_conv_w8f_np<2, kOutBF16>(g, st);
     return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
 }
+
+// ---- dense layers with a stride / padding per axis or a dilation ----------------------------------------
+// The implicit-GEMM kernel addresses a window through byte strides, so these layers ride it: the padded copy gets one
+// border width P = the largest of the four paddings and the windows start (P - pad_top) rows and (P - pad_left) pixels
+// into it (W8fArgs::origin); the strides of the two axes and a dilation along y are strides of that addressing; under a
+// dilation along x every tap becomes a run of its own (W8fArgs::kwt), Cp elements of one pixel.
+namespace {
+
+bool make_conv_w8_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t sh,
+                             int64_t sw, int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh, int64_t dw, ConvW8Geom& g,
+                             int64_t& P, int64_t& rows, int64_t& kw_run) {
+    if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
+        pt < 0 || pb < 0 || pl < 0 || pr < 0)
+        return false;
+    const int64_t eh = dh * (KH - 1) + 1, ew = dw * (KW - 1) + 1;
+    if (H + pt + pb < eh || W + pl + pr < ew) return false;
+    P = std::max(std::max(pt, pb), std::max(pl, pr));
+    rows = dw == 1 ? KH : KH * KW;
+    kw_run = dw == 1 ? KW : 1;
+    g = ConvW8Geom{B, Cin, H, W, Cout, KH, KW, sh, P, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, H, W};
+    g.Hp = H + 2 * P;
+    g.Wp = W + 2 * P;
+    g.Ho = (H + pt + pb - eh) / sh + 1;
+    g.Wo = (W + pl + pr - ew) / sw + 1;
+    g.Cp = round_up(Cin, 8);
+    g.L = kw_run * g.Cp;
+    g.Lp = round_up(g.L, 16);
+    g.K = rows * g.Lp;
+    g.M = B * g.Ho * g.Wo;
+    g.plane_bytes = round_up(B * g.Hp * g.Wp * g.Cp * 2, 256);
+    g.wp_bytes = round_up(Cout * g.K, 256);
+    return true;
+}
+
+}  // namespace
+
+namespace miq {
+
+size_t conv2d_w8_dense_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH, int64_t KW,
+                                 int64_t sh, int64_t sw, int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh, int64_t dw) {
+    ConvW8Geom G;
+    int64_t P, rows, kw_run;
+    if (!make_conv_w8_dense_geom(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, G, P, rows, kw_run) || G.M == 0 ||
+        Cout == 0)
+        return 0;
+    // (0 as well for what the kernel's 32-bit offsets do not reach: the caller then takes the direct convolution)
+    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    if (planes * G.plane_bytes >= (1ll << 31) || Cout * G.K >= (1ll << 31) || G.M >= (1ll << 31) || G.K * G.Lp >= (1ll << 31) ||
+        B * (ceil_div(H * W, 64) * ceil_div(G.Cp, 64) + 8192) >= (1ll << 31))
+        return 0;
+    return static_cast<size_t>(planes * G.plane_bytes + G.wp_bytes);
+}
+
+// The caller (miq_conv2d_general) has checked pointers, dtypes and the alignment of x / out / bias / alpha.
+int conv2d_w8_dense(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                    int64_t KH, int64_t KW, int64_t sh, int64_t sw, int64_t pt, int64_t pb, int64_t pl, int64_t pr, int64_t dh,
+                    int64_t dw, const float* bias, const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                    size_t workspace_bytes, hipStream_t st) {
+    ConvW8Geom G;
+    int64_t P, rows, kw_run;
+    MIQ_REQUIRE(make_conv_w8_dense_geom(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, G, P, rows, kw_run), MIQ_EINVAL,
+                "miq_conv2d_general: bad geometry");
+    if (G.M == 0 || Cout == 0) return MIQ_OK;
+    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
+                MIQ_ERANGE, "miq_conv2d_general: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
+    const size_t need = conv2d_w8_dense_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE, "miq_conv2d_general: needs %zu bytes of workspace (got %zu)",
+                need, workspace_bytes);
+    MIQ_REQUIRE(aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_general: workspace must be 256-byte aligned");
+    uint16_t* xp = static_cast<uint16_t*>(workspace);
+    int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
+    if (int rc = conv_w8_relayout(x, x_dtype, w, xp, wp, G, B, Cin, Cout, rows, kw_run, P, st)) return rc;
+
+    W8fArgs g{xp, wp, bias, alpha, out, beta, static_cast<int>(G.M), static_cast<int>(Cout), static_cast<int>(G.K),
+              static_cast<uint32_t>(G.plane_bytes), 0, 0, 0,
+              static_cast<int>(G.Ho * G.Wo), static_cast<int>(G.Wo), static_cast<int>(sh), static_cast<int>(G.Lp),
+              static_cast<int>(G.L), static_cast<uint32_t>(G.Wp * G.Cp * 2), static_cast<uint32_t>(G.Cp * 2),
+              static_cast<uint32_t>(G.Hp * G.Wp * G.Cp * 2),
+              static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Lp)) + 1u};
+    g.cstride_x = static_cast<int>(sw);
+    g.krow_bytes = static_cast<uint32_t>(dh * G.Wp * G.Cp * 2);
+    g.origin = static_cast<uint32_t>(((P - pt) * G.Wp + (P - pl)) * G.Cp * 2);
+    if (dw > 1) {
+        g.kwt = static_cast<int>(KW);
+        g.kwt_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(KW)) + 1u;
+        g.tap_bytes = static_cast<uint32_t>(dw * G.Cp * 2);
+    }
+    if (planes == 2) return out_dtype == MIQ_F32 ? launch_conv_w8f_np<2, kOutF32>(g, st) : launch_conv_w8f_np<2, kOutBF16>(g, st);
+    return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
+}
+
+}  // namespace miq

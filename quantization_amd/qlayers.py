@@ -4,10 +4,11 @@
 forward():
   * int8 activations take the int8 MFMA path: ONE kernel computes the integer product and the
     layer's whole floating-point tail (bias, per-channel scale, output zero point);
-  * floating-point activations (what the reference's layers are fed) keep the reference's
-    arithmetic: a library float GEMM / convolution on the int8-valued weights, followed by the
-    same tail as one HIP kernel.  The float copy of the weight is cached instead of being
-    re-created on every call (quant/Weight_Only/Quantizer.py:73,79 casts per call).
+  * floating-point activations (what the reference's layers are fed) multiply by the int8 weight
+    as it is stored (widened in registers; the reference casts the whole weight per call,
+    quant/Weight_Only/Quantizer.py:73,79), with the same tail fused;
+  * Conv2d layers with dilation, groups, a stride or padding per axis, or padding='valid' / 'same'
+    take the direct convolution kernel (miq_conv2d_general), int8 and floating-point alike.
 Host tensors are staged to the GPU and results returned to the caller's device.
 """
 import functools
@@ -15,7 +16,6 @@ import warnings
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _native
 from .qop import QopWeightActivation, QopWeightOnly, _to_gpu
@@ -35,6 +35,12 @@ def _uniform(v):
     return not isinstance(v, (tuple, list)) or len(set(v)) == 1
 
 
+def _plain_conv(stride, padding, dilation, groups):
+    """What the MFMA convolution kernels take: dilation 1, groups 1, one stride and one numeric padding for both axes."""
+    return (not isinstance(padding, str) and _uniform(dilation) and _single(dilation) == 1 and groups == 1
+            and _uniform(stride) and _uniform(padding))
+
+
 class _QuantizerBase(nn.Module):
     def _init_common(self, in_features, out_features, kernel_size, stride, padding, dilation, groups, cnn,
                      data_metrics):
@@ -52,8 +58,6 @@ class _QuantizerBase(nn.Module):
         # Placeholder until from_float() installs the quantized weight (the reference registers a
         # random fp16 tensor of this shape, Quantizer.py:34).
         self.register_buffer("weight", torch.zeros(self.weight_shape, dtype=torch.int8))
-        self._wfloat = None
-        self._wfloat_src = None
         self._gpu_cache = {}      # device copies of host-resident weight / bias / scales, keyed by role
         self._beta_cache = None   # (output_zero_point tensor, its version, the value as a Python float)
         self._params_stale = None # set to a message when a checkpoint without quantization parameters was loaded
@@ -67,7 +71,6 @@ class _QuantizerBase(nn.Module):
         return self
 
     def _invalidate(self):
-        self._wfloat = None
         self._gpu_cache = {}
         self._beta_cache = None
 
@@ -126,12 +129,11 @@ class _QuantizerBase(nn.Module):
     def _int8_product(self, x, bias, alpha, beta):
         w = self._on_gpu("weight", self.weight)
         if self.cnn:
-            if _single(self.dilation) != 1 or self.groups != 1:
-                raise NotImplementedError("the int8 convolution implements dilation 1, groups 1")
-            if isinstance(self.padding, str):
-                raise NotImplementedError("string padding modes are not implemented")
-            return _native.conv2d_i8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha,
-                                     beta=beta)
+            if _plain_conv(self.stride, self.padding, self.dilation, self.groups):
+                return _native.conv2d_i8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha,
+                                         beta=beta)
+            return _native.conv2d_general(x, w, self.stride, self.padding, self.dilation, self.groups, bias=bias,
+                                          alpha=alpha, beta=beta)
         lead = x.shape[:-1]
         y = _native.gemm_i8(x.reshape(-1, x.shape[-1]).contiguous(), w, bias=bias, alpha=alpha, beta=beta)
         return y.view(*lead, y.shape[-1])
@@ -147,19 +149,18 @@ class _QuantizerBase(nn.Module):
             out = _native.gemm_w8(x.reshape(-1, x.shape[-1]).contiguous(), w, bias=bias, alpha=alpha, beta=beta)
             return out.view(*lead, out.shape[-1])
         # Conv2d: the same product as an implicit GEMM (miq_conv2d_w8) for what that kernel covers ...
-        if (not isinstance(self.padding, str) and _uniform(self.dilation) and _single(self.dilation) == 1
-                and self.groups == 1 and _uniform(self.stride) and _uniform(self.padding) and x.dim() == 4):
-            if x.dtype == torch.float64:
-                x = x.to(torch.float32)
-            return _native.conv2d_w8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha, beta=beta)
-        # ... and otherwise (dilation, groups, unequal strides, string padding) a library float convolution on a
-        # cached float copy of the weight, then the fused bias / scale epilogue.
-        if self._wfloat is None or self._wfloat.dtype != x.dtype or self._wfloat.device != w.device \
-                or self._wfloat_src is not self.weight:
-            self._wfloat, self._wfloat_src = w.to(x.dtype), self.weight
-        y = F.conv2d(x, self._wfloat, stride=self.stride, padding=self.padding, dilation=self.dilation,
-                     groups=self.groups)
-        return _native.epilogue_channels_f32(y.contiguous(), bias, alpha, beta)
+        if x.dtype == torch.float64:
+            x = x.to(torch.float32)
+        batched = x.dim() == 4
+        if not batched:   # F.conv2d also takes one image [C, H, W]
+            x = x.unsqueeze(0)
+        if _plain_conv(self.stride, self.padding, self.dilation, self.groups):
+            y = _native.conv2d_w8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha, beta=beta)
+        else:
+            # ... and otherwise (dilation, groups, a stride / padding per axis, string padding) the direct convolution
+            y = _native.conv2d_general(x, w, self.stride, self.padding, self.dilation, self.groups, bias=bias,
+                                       alpha=alpha, beta=beta)
+        return y if batched else y.squeeze(0)
 
     def _run(self, x, bias, alpha, beta):
         if self._params_stale:
@@ -250,10 +251,8 @@ class WeightOnlyQuantizer(_QuantizerBase):
             bias = None if self.bias is None else _to_gpu(self.bias.detach())
             xg = _to_gpu(x).to(torch.float32)
             if self.cnn:
-                if _single(self.dilation) != 1 or self.groups != 1 or isinstance(self.padding, str):
-                    raise NotImplementedError("the int8 convolution implements dilation 1, groups 1, numeric padding")
-                y = conv2d_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum, _single(self.stride),
-                                        _single(self.padding))
+                y = conv2d_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum, self.stride, self.padding,
+                                        dilation=self.dilation, groups=self.groups)
             else:
                 y = linear_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum)
             return y.to(home)

@@ -68,6 +68,21 @@ def test_argument_validation_needs_no_device():
         lib.miq_conv2d_w8_workspace(0, 4, 64, 28, 28, 128, 1, 1, 1, 0)
     # ... but not with padding or a larger filter
     assert lib.miq_conv2d_i8_workspace(2, 64, 56, 56, 128, 1, 1, 2, 1) == 2 * 58 * 58 * 64 + 128 * 64
+    # the general convolution: groups must divide the channels, MIQ_I32 needs int8 activations, the dilated filter must
+    # fit the padded image; an empty batch succeeds
+    p64 = ctypes.c_void_p(64)
+    general = lambda xdt, C, Co, k, pad, dil, groups, odt, B=1: lib.miq_conv2d_general(  # noqa: E731
+        p64, xdt, p64, B, C, 8, 8, Co, k, k, 1, 1, pad, pad, pad, pad, dil, dil, groups, null, p64, 0.0, p64, odt, null, 0, null)
+    assert general(4, 6, 8, 3, 1, 1, 4, 0) == -1 and b"groups" in lib.miq_last_error()
+    assert general(0, 4, 4, 3, 1, 1, 1, 3) == -1 and b"MIQ_I32" in lib.miq_last_error()
+    assert general(4, 4, 4, 3, 0, 4, 1, 0) == -1 and b"larger" in lib.miq_last_error()
+    assert general(9, 4, 4, 3, 1, 1, 1, 0) == -1 and b"x_dtype" in lib.miq_last_error()
+    assert general(4, 4, 4, 3, 1, 1, 2, 0, B=0) == 0
+    # a dense layer wants its workspace (padded channels-last copy, border 2 all round, + packed weight: nine taps of 16 bytes
+    # per output channel under a dilation along x); a grouped one none
+    assert general(4, 4, 4, 3, 2, 2, 1, 0) == -3 and b"workspace" in lib.miq_last_error()
+    assert lib.miq_conv2d_general_workspace(4, 1, 4, 8, 8, 4, 3, 3, 1, 1, 2, 2, 2, 2, 2, 2, 1) == 768 + 768   # 12*12*4 and 4*9*16 bytes, each rounded up to 256
+    assert lib.miq_conv2d_general_workspace(4, 1, 4, 8, 8, 4, 3, 3, 1, 1, 2, 2, 2, 2, 2, 2, 2) == 0
     # the allocation-free variant refuses, before any device call, what its built-in 32 MiB do not hold
     assert lib.miq_gemm_i8_noalloc_max_workspace() == 32 << 20
     assert lib.miq_gemm_i8_noalloc(ctypes.c_void_p(64), ctypes.c_void_p(64), 1, 16, 8192, 8192, null, ctypes.c_void_p(64),

@@ -1,0 +1,180 @@
+"""Conv2d with dilation, groups, a stride / padding per axis and string padding (miq_conv2d_general, through the C ABI and
+the drop-in layers) against F.conv2d.
+
+The reference's layers forward all of these arguments to F.conv2d (quant/Weight_Only/Quantizer.py:73,
+quant/Weight_Activation/Quantizer.py:53-56).  int8 activations are held to bit-exactness against the same convolution
+in float64 (exact on these integers: the reference's own acceptance check for its int8 kernel,
+cuda_kernels/conv2d_int8/test.py:27-33) and, with an epilogue, against the oracle's (acc + bias) * alpha + beta;
+floating-point activations to 5e-5 of the sum of magnitudes per element, far inside the 1e-3 relative of the
+weight-only path.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+Q_PARAMS = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+
+
+@pytest.fixture(scope="module")
+def N():
+    from quantization_amd import _native
+    _native.lib()
+    return _native
+
+
+def rand_i8(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-128, 128, shape, generator=g, dtype=torch.int32).to(torch.int8)
+
+
+# B, Cin, H, W, Cout, (KH, KW), stride, padding, dilation, groups
+CASES = [
+    (2, 8, 12, 12, 16, (3, 3), 1, 2, 2, 1),              # dilation 2
+    (2, 8, 13, 11, 6, (3, 3), (2, 1), (1, 2), 1, 1),     # a stride and a padding per axis
+    (3, 16, 10, 10, 24, (3, 3), 1, 1, 1, 4),             # groups: 4 input, 6 output channels each (thin groups)
+    (2, 32, 9, 9, 32, (3, 3), 1, 1, 1, 32),              # depthwise
+    (2, 12, 9, 9, 36, (3, 3), 2, 1, 1, 12),              # depthwise with a channel multiplier of 3, stride 2
+    (2, 64, 8, 8, 80, (3, 3), 1, 1, 1, 2),               # 40 output channels a group: one ragged 64-channel block
+    (1, 40, 7, 9, 150, (3, 3), 1, "same", (2, 3), 1),    # 'same' under a dilation per axis; three channel blocks, 360 taps
+    (2, 6, 10, 10, 10, (4, 2), 1, "same", 1, 2),         # 'same' on even filter extents: one more row / column behind
+    (2, 4, 11, 13, 9, (5, 3), (1, 2), "valid", 1, 1),    # 'valid', a filter that is not square
+    (1, 3, 40, 40, 8, (7, 7), (2, 3), (3, 0), (1, 2), 1),
+    (2, 16, 20, 300, 16, (1, 5), 1, (0, 2), 1, 16),      # depthwise 1 x 5 over rows longer than a block of pixels
+    (1, 1, 5, 5, 1, (3, 3), 1, 0, 1, 1),
+    (70, 4, 6, 6, 4, (3, 3), 1, 1, 2, 2),                # many images
+    # thin groups on images of 2048 output pixels and more: four pixels a lane (1, 8 and 4 channels a lane)
+    (2, 8, 50, 47, 8, (3, 3), 1, 1, 1, 8), (1, 8, 48, 48, 24, (3, 3), 1, 1, 1, 4), (1, 6, 100, 100, 9, (3, 3), 2, 1, 1, 3),
+    # dense layers large enough for every tile shape of the implicit-GEMM kernels
+    (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
+    (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
+    (8, 256, 14, 14, 256, (3, 3), 1, 2, 2, 1),
+]
+
+
+def torch_args(stride, padding, dilation, groups):
+    return dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p,d,g", CASES)
+def test_int8_raw_sums_are_exact(N, B, C, H, W, Co, k, s, p, d, g):
+    x, w = rand_i8((B, C, H, W), B + C), rand_i8((Co, C // g, *k), Co + H)
+    ref = F.conv2d(x.cuda().double(), w.cuda().double(), **torch_args(s, p, d, g)).to(torch.int32)
+    out = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, out_dtype=torch.int32)
+    assert out.shape == ref.shape and out.dtype == torch.int32
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p,d,g", CASES[:8])
+def test_int8_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p, d, g):
+    x, w = rand_i8((B, C, H, W), 5), rand_i8((Co, C // g, *k), 6)
+    gen = torch.Generator().manual_seed(4)
+    alpha, bias = torch.rand(Co, generator=gen) * 0.02, torch.randn(Co, generator=gen) * 30
+    acc = F.conv2d(x.double(), w.double(), **torch_args(s, p, d, g)).to(torch.int32).numpy()
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), -1.25)
+    out = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    outb = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25,
+                            out_dtype=torch.bfloat16)
+    np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
+    # no bias
+    ref0 = OC.epilogue_f32(acc, np.zeros(Co, np.float32), alpha.numpy(), 0.0)
+    out0 = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, alpha=alpha.cuda())
+    np.testing.assert_array_equal(out0.cpu().numpy(), ref0)
+
+
+@pytest.mark.parametrize("xdt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,Co,k,s,p,d,g", CASES)
+def test_float_activations(N, B, C, H, W, Co, k, s, p, d, g, xdt):
+    gen = torch.Generator().manual_seed(B * 100 + C + Co)
+    x = torch.randn(B, C, H, W, generator=gen).to(DT[xdt])
+    w = rand_i8((Co, C // g, *k), Co)
+    alpha = torch.rand(Co, generator=gen) * 0.02 + 1e-4
+    b = torch.randn(Co, generator=gen) * 5
+    out_dtype = torch.bfloat16 if (B + Co) % 2 else torch.float32
+    y = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, bias=b.cuda(), alpha=alpha.cuda(), beta=0.25, out_dtype=out_dtype)
+    a4 = alpha.double().view(1, -1, 1, 1)
+    kw = torch_args(s, p, d, g)
+    ref = (F.conv2d(x.double(), w.double(), **kw) + b.double().view(1, -1, 1, 1)) * a4 + 0.25
+    mag = (F.conv2d(x.double().abs(), w.double().abs(), **kw) + b.double().abs().view(1, -1, 1, 1)) * a4 + 0.25
+    assert tuple(y.shape) == tuple(ref.shape) and y.dtype == out_dtype
+    tol = 5e-5 * mag + 1e-30
+    if out_dtype == torch.bfloat16:
+        tol = tol + ref.abs() * 2.0 ** -8
+    worst = float(((y.cpu().double() - ref).abs() / tol).max())
+    assert worst <= 1.0, f"worst error / tolerance = {worst:.3f}"
+
+
+def test_rejects_what_conv2d_rejects(N):
+    x, w = rand_i8((1, 4, 8, 8), 1).cuda(), rand_i8((4, 2, 3, 3), 2).cuda()
+    a = torch.ones(4, device="cuda")
+    with pytest.raises(RuntimeError, match="same"):
+        N.conv2d_general(x, w, 2, "same", 1, 2, alpha=a)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        N.conv2d_general(x, w, 1, 0, 1, 1, alpha=a)          # the kernel has Cin / 2 channels
+    with pytest.raises(RuntimeError, match="larger than the padded input"):
+        N.conv2d_general(x, w, 1, 0, 4, 2, alpha=a)          # dilated extent 9 > 8
+    with pytest.raises(RuntimeError, match="alpha"):
+        N.conv2d_general(x, w, 1, 0, 1, 2)
+    with pytest.raises(RuntimeError, match="output dtype"):
+        N.conv2d_general(x.float(), w, 1, 0, 1, 2, alpha=a, out_dtype=torch.int32)
+
+
+LAYERS = [
+    dict(in_channels=8, out_channels=12, kernel_size=3, stride=1, padding=2, dilation=2, groups=1),
+    dict(in_channels=16, out_channels=16, kernel_size=3, stride=2, padding=1, groups=16),
+    dict(in_channels=8, out_channels=8, kernel_size=(3, 5), stride=(1, 2), padding=(1, 2), groups=2),
+    dict(in_channels=6, out_channels=10, kernel_size=4, padding="same", groups=2, bias=False),
+]
+
+
+@pytest.mark.parametrize("kw", LAYERS)
+def test_weight_only_layer_forward(kw):
+    """The drop-in layer on such a Conv2d: y = scale[n] * (conv(x, Wq) + b[n]) (quant/Weight_Only/Quantizer.py:73-86), for
+    floating-point activations (within 1e-3 relative) and for int8 activations (the integers are exact, so the fp32
+    epilogue is the only rounding)."""
+    from quantization_amd.qlayers import WeightOnlyQuantizer
+    torch.manual_seed(3)
+    m = nn.Conv2d(**kw).cuda()
+    q = WeightOnlyQuantizer.from_float(m, data_metry=Q_PARAMS)
+    assert "QConv2d" in repr(q)
+    x = torch.randn(3, kw["in_channels"], 14, 15, device="cuda")
+    args = dict(stride=m.stride, padding=m.padding, dilation=m.dilation, groups=m.groups)
+    scale = q.weight_quant.scales.reshape(1, -1, 1, 1).double()
+    b = 0.0 if m.bias is None else m.bias.detach().double().view(1, -1, 1, 1)
+    ref = (F.conv2d(x.double(), q.weight.double(), **args) + b) * scale
+    y = q(x)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    # one image without the batch axis, as F.conv2d takes it
+    y1 = q(x[0])
+    assert y1.shape == ref.shape[1:] and torch.equal(y1, y[0])
+    xi = torch.randint(-128, 128, x.shape, device="cuda", dtype=torch.int32).to(torch.int8)
+    refi = (F.conv2d(xi.double(), q.weight.double(), **args) + b) * scale
+    yi = q(xi)
+    np.testing.assert_allclose(yi.cpu().numpy(), refi.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(refi.abs().max()))
+
+
+def test_weight_only_layer_with_input_quant_on_a_grouped_dilated_conv():
+    """input_quant on such a layer: the activation quantised per tensor into a frame of its zero point, then the int8
+    direct convolution: equal to convolving the dequantised activation in float64."""
+    from quantization_amd.activation import quantize_tensor_i8
+    from quantization_amd.qlayers import WeightOnlyQuantizer
+    torch.manual_seed(5)
+    m = nn.Conv2d(8, 12, 3, stride=(2, 1), padding=(2, 1), dilation=(2, 1), groups=4).cuda()
+    q = WeightOnlyQuantizer.from_float(m, data_metry=Q_PARAMS)
+    q.input_quant = True
+    x = torch.randn(2, 8, 12, 12, device="cuda") + 0.3
+    xq, sx, zp = quantize_tensor_i8(x)
+    xhat = (xq.double() - zp.double()) * sx.double()
+    ref = (F.conv2d(xhat, q.weight.double(), None, m.stride, m.padding, m.dilation, m.groups) +
+           m.bias.detach().double().view(1, -1, 1, 1)) * q.weight_quant.scales.reshape(1, -1, 1, 1).double()
+    y = q(x)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
