@@ -33,7 +33,7 @@ struct GeneralArgs {
     const float* alpha;
     float beta;
     void* out;
-    int Cin, H, W, Cout, KH, KW;
+    int B, Cin, H, W, Cout, KH, KW;
     int sh, sw, pt, pl, dh, dw;
     int cin_g, cout_g;   // channels per group
     int cblocks;         // channel blocks per group
@@ -69,19 +69,29 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
     const int pw = wave % PW, cw = wave / PW;
     const int grp = blockIdx.y / g.cblocks, cb = blockIdx.y - grp * g.cblocks;
     const int co_wg = cb * kCB;   // the workgroup's first channel inside its group
-    const int b = blockIdx.z;
+    // Thin layers (PW == 4) deal the output pixels of the whole batch over the lanes, image after image: a small image alone
+    // would not fill a workgroup, and all images share the channel block's weights.  Otherwise blockIdx.z is the image.
+    constexpr bool kFlat = PW == 4;
     const int HoWo = g.Ho * g.Wo;
-    int p[NPB], ih0[NPB], iw0[NPB];
+    int p[NPB], ih0[NPB], iw0[NPB], img[NPB];
     bool live[NPB];
 #pragma unroll
     for (int q = 0; q < NPB; ++q) {
         p[q] = ((blockIdx.x * PW + pw) * NPB + q) * 64 + lane;
-        live[q] = p[q] < HoWo;
+        if constexpr (kFlat) {
+            live[q] = p[q] < g.B * HoWo;   // (B * HoWo and B * Cin * H * W fit 31 bits: checked by the host)
+            img[q] = p[q] / HoWo;
+            p[q] -= img[q] * HoWo;
+        } else {
+            live[q] = p[q] < HoWo;
+            img[q] = blockIdx.z;
+        }
         const int ho = p[q] / g.Wo, wo = p[q] - ho * g.Wo;
         ih0[q] = ho * g.sh - g.pt;
         iw0[q] = wo * g.sw - g.pl;
     }
-    const T* xg = static_cast<const T*>(g.x) + (static_cast<int64_t>(b) * g.Cin + grp * g.cin_g) * g.H * g.W;
+    const T* xg = static_cast<const T*>(g.x) + (static_cast<int64_t>(kFlat ? 0 : blockIdx.z) * g.Cin + grp * g.cin_g) * g.H * g.W;
+    const int img_elems = g.Cin * g.H * g.W;
     const int8_t* wg = g.w + static_cast<int64_t>(grp * g.cout_g + co_wg) * g.R;
     const int khw = g.KH * g.KW;
 
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
                 const int ih = ih0[q] + kh * g.dh, iw = iw0[q] + kw * g.dw;
                 xv[q] = 0;
                 if (live[q] && static_cast<unsigned>(ih) < static_cast<unsigned>(g.H) && static_cast<unsigned>(iw) < static_cast<unsigned>(g.W))
-                    xv[q] = load_x(xg + (ci * g.H + ih) * g.W + iw);   // (one image's elements fit 31 bits: checked by the host)
+                    xv[q] = load_x(xg + (kFlat ? img[q] * img_elems : 0) + (ci * g.H + ih) * g.W + iw);   // (31 bits: checked by the host)
             }
             if (++kw == g.KW) {
                 kw = 0;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
             const int co = co_wg + cw * kCo + j;
             if (co >= g.cout_g) break;
             const int n = grp * g.cout_g + co;
-            const int64_t idx = (static_cast<int64_t>(b) * g.Cout + n) * HoWo + p[q];
+            const int64_t idx = (static_cast<int64_t>(img[q]) * g.Cout + n) * HoWo + p[q];
             if constexpr (OUT == MIQ_I32) {
                 static_cast<int*>(g.out)[idx] = static_cast<int>(acc[q][j]);
             } else {
@@ -176,14 +186,18 @@ template <typename T, int OUT>
 int launch_general(const GeneralArgs& a0, int64_t B, int64_t groups, hipStream_t st) {
     GeneralArgs a = a0;
     const int64_t HoWo = static_cast<int64_t>(a.Ho) * a.Wo;
-    const bool thin = a.cout_g <= 8;   // depthwise and thin groups: every wave on pixels, one block of 1, 4 or 8 channels
-    const bool many = thin && HoWo >= 2048;   // ... and four pixels a lane once an image has workgroups' worth of them
-    const int cb = !thin ? 64 : a.cout_g == 1 ? 1 : a.cout_g <= 4 ? 4 : 8, px = many ? 1024 : thin ? 256 : 64;
+    // depthwise and thin groups: every wave on pixels (of the whole batch), one block of 1, 4 or 8 channels ...
+    const bool thin = a.cout_g <= 8 && B * HoWo < (1ll << 31) && B * a.Cin * a.H * a.W < (1ll << 31);
+    const int cb = !thin ? 64 : a.cout_g == 1 ? 1 : a.cout_g <= 4 ? 4 : 8;
     a.cblocks = static_cast<int>(ceil_div(a.cout_g, cb));
-    const int64_t gx = ceil_div(HoWo, px), gy = groups * a.cblocks;
+    a.B = static_cast<int>(B);
+    const int64_t gy = groups * a.cblocks;
+    // ... and four pixels a lane once that still leaves every CU a few workgroups
+    const bool many = thin && ceil_div(B * HoWo, 1024) * gy >= 1024;
+    const int64_t gx = thin ? ceil_div(B * HoWo, many ? 1024 : 256) : ceil_div(HoWo, 64);
     MIQ_REQUIRE(gx < (1ll << 31) && gy <= 65535 && B <= 65535, MIQ_ERANGE,
                 "miq_conv2d_general: more than 65535 images or channel blocks (B=%lld, blocks=%lld)", (long long)B, (long long)gy);
-    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(B));
+    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(thin ? 1 : B));
     if (cb == 1 && many)
         conv_general_kernel<T, OUT, 4, 1, 4><<<grid, 256, 0, st>>>(a);
     else if (cb == 1)

@@ -50,8 +50,10 @@ CASES = [
     (2, 16, 20, 300, 16, (1, 5), 1, (0, 2), 1, 16),      # depthwise 1 x 5 over rows longer than a block of pixels
     (1, 1, 5, 5, 1, (3, 3), 1, 0, 1, 1),
     (70, 4, 6, 6, 4, (3, 3), 1, 1, 2, 2),                # many images
-    # thin groups on images of 2048 output pixels and more: four pixels a lane (1, 8 and 4 channels a lane)
-    (2, 8, 50, 47, 8, (3, 3), 1, 1, 1, 8), (1, 8, 48, 48, 24, (3, 3), 1, 1, 1, 4), (1, 6, 100, 100, 9, (3, 3), 2, 1, 1, 3),
+    # thin groups: the batch's pixels dealt over the lanes image after image (workgroups that span images, 1 / 8 / 4 channels
+    # a lane), and with enough of them for four workgroups a CU four pixels a lane
+    (2, 8, 50, 47, 8, (3, 3), 1, 1, 1, 8), (5, 8, 9, 11, 24, (3, 3), 1, 1, 1, 4), (3, 6, 20, 20, 9, (3, 3), 2, 1, 1, 3),
+    (8, 64, 48, 47, 64, (3, 3), 1, 1, 1, 64), (8, 64, 64, 64, 96, (3, 3), 1, 1, 1, 32), (8, 32, 64, 63, 192, (3, 3), 1, 1, 2, 32),
     # dense layers large enough for every tile shape of the implicit-GEMM kernels
     (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
     (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
