@@ -318,6 +318,35 @@ def conv_weight_only_float(N_, dev):
     return res
 
 
+def conv_general(N_, dev):
+    """Layers the reference hands to F.conv2d with arguments its own int8 kernel lacks (quant/Weight_Only/Quantizer.py:73):
+    a dilated dense layer (the implicit-GEMM MFMA kernels with generalised window strides) and a depthwise and a grouped
+    one (direct convolution, HBM-bound by construction), through miq_conv2d_general: whole calls, HIP events, fp32 out."""
+    layers = [("dilated_3x3_d2_256ch_28x28_b32", 32, 256, 28, 256, 3, 1, 2, 2, 1),
+              ("depthwise_3x3_32ch_112x112_b64", 64, 32, 112, 32, 3, 1, 1, 1, 32),
+              ("grouped_3x3_g32_128ch_56x56_b32", 32, 128, 56, 128, 3, 1, 1, 1, 32)]
+    res = {}
+    for name, B, C, H, Co, k, s, p, d, g in layers:
+        w = torch.randint(-128, 128, (Co, C // g, k, k), dtype=torch.int32, device=dev).to(torch.int8)
+        alpha = torch.rand(Co, device=dev) * 1e-3
+        ent = {}
+        for dt in (torch.int8, torch.float32):
+            x = (torch.randint(-128, 128, (B, C, H, H), dtype=torch.int32, device=dev).to(torch.int8) if dt == torch.int8
+                 else torch.randn(B, C, H, H, device=dev))
+            y = N_.conv2d_general(x, w, s, p, d, g, alpha=alpha)
+            ms = median_ms(lambda: N_.conv2d_general(x, w, s, p, d, g, alpha=alpha, out=y), 10, 5)
+            ops = 2.0 * y.numel() * (C // g) * k * k
+            nbytes = x.numel() * x.element_size() + y.numel() * 4 + w.numel()
+            e = {"call_ms": round(ms, 4), "TOPS": round(ops / (ms * 1e-3) / 1e12, 2)}
+            if g > 1:
+                e["roofline"] = hbm_roofline(nbytes, ms)
+            else:
+                e["roofline"] = mfma_roofline(ops, ms, PEAK_INT8_TOPS if dt == torch.int8 else PEAK_BF16_TFLOPS)
+            ent[str(dt).split(".")[-1]] = e
+        res[name] = ent
+    return res
+
+
 def config5(N_, dev, world, rank, dist, m_list=(256, 2048, 8192)):
     """BASELINE config 5: Llama-3-70B linear shapes split by output channel over the `world` ranks (strong scaling:
     the layer is fixed, each rank owns N / world channels), int8 activations, bf16 epilogue output written straight
@@ -631,6 +660,7 @@ def main():
             line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
             line["extra"]["conv_int8"] = conv_int8(N_, dev)
             line["extra"]["conv_weight_only_float"] = conv_weight_only_float(N_, dev)
+            line["extra"]["conv_general"] = conv_general(N_, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
         print(json.dumps(line), flush=True)
