@@ -182,9 +182,125 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
     }
 }
 
+// Depthwise layers (one input and one output channel a group) with stride 1 and dilation 1 along x and a filter 3, 5 or 7
+// wide: a lane owns four consecutive outputs of one output row and, per filter row, loads the KW + 3 activations under
+// them once (the kernel above loads KW per output and checks every one against the image: four times the instructions
+// of the arithmetic).  The units (image, channel, row, quad of pixels) are dealt over the lanes in that order, so small
+// images fill workgroups too; a lane reads its channel's filter straight from memory (KH * KW cached bytes).
+template <typename T, int OUT, int KW>
+__global__ __launch_bounds__(256) void conv_depthwise_rows_kernel(GeneralArgs g, uint32_t units, int quads, int vec_in, int vec_out) {
+    using Acc = std::conditional_t<std::is_same_v<T, int8_t>, int, float>;
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= units) return;
+    const uint32_t rowid = u / quads;                 // (image * C + channel) * Ho + ho
+    const int wo0 = static_cast<int>(u - rowid * quads) * 4;
+    const uint32_t plane = rowid / g.Ho;              // image * C + channel
+    const int ho = static_cast<int>(rowid - plane * g.Ho);
+    const int c = static_cast<int>(plane % g.Cout);
+    const T* xp = static_cast<const T*>(g.x) + static_cast<size_t>(plane) * g.H * g.W;   // (Cin == Cout)
+    const int8_t* wc = g.w + c * g.KH * KW;
+    const int iw0 = wo0 - g.pl;
+    bool col_ok[KW + 3];
+#pragma unroll
+    for (int k = 0; k < KW + 3; ++k) col_ok[k] = static_cast<unsigned>(iw0 + k) < static_cast<unsigned>(g.W);
+    Acc acc[4] = {0, 0, 0, 0};
+    for (int kh = 0; kh < g.KH; ++kh) {
+        const int ih = ho * g.sh - g.pt + kh * g.dh;
+        if (static_cast<unsigned>(ih) >= static_cast<unsigned>(g.H)) continue;
+        const T* xr = xp + ih * g.W + iw0;
+        Acc xv[KW + 3];
+        if (vec_in) {
+            // (wave-uniform) the four activations under the lane's own outputs, columns wo0 .. wo0 + 3 = k in [pl, pl + 3], are one
+            // aligned vector inside the image (W % 4 == 0, aligned planes); only the KW - 1 beside them are single loads
+            struct alignas(4 * sizeof(T)) Vec4 {
+                T e[4];
+            };
+            const Vec4 v = *reinterpret_cast<const Vec4*>(xr + g.pl);
+#pragma unroll
+            for (int k = 0; k < KW + 3; ++k) {
+                xv[k] = 0;
+                if (k >= g.pl && k < g.pl + 4) {
+                    const T e = k - g.pl == 0 ? v.e[0] : k - g.pl == 1 ? v.e[1] : k - g.pl == 2 ? v.e[2] : v.e[3];
+                    xv[k] = load_x(&e);
+                } else if (col_ok[k]) {
+                    xv[k] = load_x(xr + k);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KW + 3; ++k) {
+                xv[k] = 0;
+                if (col_ok[k]) xv[k] = load_x(xr + k);
+            }
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const Acc wv = static_cast<Acc>(wc[kh * KW + kw]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (std::is_same_v<Acc, int>)
+                    acc[e] += xv[kw + e] * wv;
+                else
+                    acc[e] = __builtin_fmaf(xv[kw + e], wv, acc[e]);
+            }
+        }
+    }
+    const size_t idx = (static_cast<size_t>(plane) * g.Ho + ho) * g.Wo + wo0;
+    float bias = 0.f, alpha = 1.f;
+    if constexpr (OUT != MIQ_I32) {
+        alpha = g.alpha[c];
+        if (g.bias) bias = g.bias[c];
+    }
+    if (vec_out) {   // (wave-uniform) Wo % 4 == 0 and an aligned output: the lane's four outputs are one vector
+        if constexpr (OUT == MIQ_I32) {
+            *reinterpret_cast<int4*>(static_cast<int*>(g.out) + idx) = int4{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]};
+        } else {
+            const float y0 = dequant1(acc[0], bias, alpha, g.beta), y1 = dequant1(acc[1], bias, alpha, g.beta),
+                        y2 = dequant1(acc[2], bias, alpha, g.beta), y3 = dequant1(acc[3], bias, alpha, g.beta);
+            if constexpr (OUT == MIQ_F32)
+                *reinterpret_cast<float4*>(static_cast<float*>(g.out) + idx) = float4{y0, y1, y2, y3};
+            else
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(g.out) + idx) = pack4_bf16(y0, y1, y2, y3);
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (wo0 + e >= g.Wo) break;
+        if constexpr (OUT == MIQ_I32) {
+            static_cast<int*>(g.out)[idx + e] = static_cast<int>(acc[e]);
+        } else {
+            const float y = dequant1(acc[e], bias, alpha, g.beta);
+            if constexpr (OUT == MIQ_F32)
+                static_cast<float*>(g.out)[idx + e] = y;
+            else
+                static_cast<uint16_t*>(g.out)[idx + e] = f32_to_bf16_bits(y);
+        }
+    }
+}
+
 template <typename T, int OUT>
 int launch_general(const GeneralArgs& a0, int64_t B, int64_t groups, hipStream_t st) {
     GeneralArgs a = a0;
+    if (a.cin_g == 1 && a.cout_g == 1 && a.sw == 1 && a.dw == 1 && (a.KW == 3 || a.KW == 5 || a.KW == 7)) {
+        const int64_t quads = ceil_div(a.Wo, 4), units = B * a.Cout * a.Ho * quads;
+        if (units < (1ll << 31) && B * a.Cin * static_cast<int64_t>(a.H) * a.W < (1ll << 31) && static_cast<int64_t>(a.H) * a.W < (1ll << 31)) {
+            const unsigned grid = static_cast<unsigned>(ceil_div(units, 256));
+            const uint32_t nu = static_cast<uint32_t>(units);
+            const int nq = static_cast<int>(quads);
+            // vectors of four: activations when every row of every plane starts on one and the lane's own four lie inside the
+            // filter's window (pad_left < KW); outputs when the output rows are whole vectors
+            const int vec_in = a.W % 4 == 0 && aligned(a.x, 4 * sizeof(T)) && a.pl <= a.KW - 1;
+            const int vec_out = a.Wo % 4 == 0 && aligned(a.out, OUT == MIQ_BF16 ? 8 : 16);
+            if (a.KW == 3)
+                conv_depthwise_rows_kernel<T, OUT, 3><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
+            else if (a.KW == 5)
+                conv_depthwise_rows_kernel<T, OUT, 5><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
+            else
+                conv_depthwise_rows_kernel<T, OUT, 7><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
+            return check_launch("conv_depthwise_rows_kernel");
+        }
+    }
     const int64_t HoWo = static_cast<int64_t>(a.Ho) * a.Wo;
     // depthwise and thin groups: every wave on pixels (of the whole batch), one block of 1, 4 or 8 channels ...
     const bool thin = a.cout_g <= 8 && B * HoWo < (1ll << 31) && B * a.Cin * a.H * a.W < (1ll << 31);

@@ -54,6 +54,10 @@ CASES = [
     # a lane), and with enough of them for four workgroups a CU four pixels a lane
     (2, 8, 50, 47, 8, (3, 3), 1, 1, 1, 8), (5, 8, 9, 11, 24, (3, 3), 1, 1, 1, 4), (3, 6, 20, 20, 9, (3, 3), 2, 1, 1, 3),
     (8, 64, 48, 47, 64, (3, 3), 1, 1, 1, 64), (8, 64, 64, 64, 96, (3, 3), 1, 1, 1, 32), (8, 32, 64, 63, 192, (3, 3), 1, 1, 2, 32),
+    # depthwise with stride 1 / dilation 1 along x and 3, 5, 7 filter columns: four outputs of a row per lane (ragged rows,
+    # a stride and a dilation along y, 'same')
+    (2, 24, 13, 17, 24, (5, 5), 1, 2, 1, 24), (3, 10, 21, 18, 10, (7, 7), (2, 1), (3, 3), (2, 1), 10),
+    (2, 6, 12, 10, 6, (2, 3), 1, "same", 1, 6), (1, 5, 8, 3, 5, (3, 3), 1, 1, 1, 5),
     # dense layers large enough for every tile shape of the implicit-GEMM kernels
     (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
     (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
