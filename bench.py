@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 dense peak of MI355X
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
+EVENT_EVERY = int(os.environ.get("MIQ_BENCH_EVENT_EVERY", "4"))   # the timed region's GEMM launches that carry a HIP event pair
 
 PREWARM_S = 0.3   # seconds of untimed load before the warm-up steps (clock ramp), reported as prewarm_s
 
@@ -523,17 +524,19 @@ def main():
         step i+1 runs on the compute stream (the steps are independent layers of a stack); two gather
         buffers alternate, and a buffer is written again only after its previous gather has completed.
         Every gather has completed when this returns.  `events` collects a HIP event pair around every
-        GEMM launch, on the stream it is launched on."""
+        EVENT_EVERY-th GEMM launch, on the stream it is launched on (an event record is a packet of its own in the queue:
+        around every launch the pairs cost the step 1-2 % of its time)."""
         pending = [None, None]
         for i in range(n):
             slot = i & 1
             if pending[slot] is not None:
                 pending[slot].wait()
-            if events is not None:
+            sample = events is not None and i % EVENT_EVERY == 0
+            if sample:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             got = layer.compute_block(x, slot)
-            if events is not None:
+            if sample:
                 e1.record()
                 events.append((e0, e1))
             pending[slot] = layer.start_gather(got)
