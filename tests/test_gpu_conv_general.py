@@ -184,3 +184,23 @@ def test_weight_only_layer_with_input_quant_on_a_grouped_dilated_conv():
            m.bias.detach().double().view(1, -1, 1, 1)) * q.weight_quant.scales.reshape(1, -1, 1, 1).double()
     y = q(x)
     np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("kw", LAYERS[:3])
+def test_weight_activation_layer_forward(kw):
+    """The weight+activation layer on such a Conv2d: y = (conv(x_q, Wq) + bias') * scalers + output_zero_point
+    (quant/Weight_Activation/Quantizer.py:53-60) on int8 activations, bit-exact against the oracle's epilogue of the exact sums."""
+    from quantization_amd.qlayers import WeightActivationQuantizer
+    torch.manual_seed(7)
+    m = nn.Conv2d(**kw).cuda()
+    q = WeightActivationQuantizer.from_float(m, data_metry=Q_PARAMS)
+    n = kw["out_channels"]
+    gen = torch.Generator().manual_seed(11)
+    q.bias = (torch.randn(n, generator=gen) * 20).cuda()
+    q.scalers = (torch.rand(n, generator=gen) * 0.01 + 1e-4).cuda()
+    q.output_zero_point = torch.tensor([3.0]).cuda()
+    xi = torch.randint(-128, 128, (2, kw["in_channels"], 11, 13), dtype=torch.int32).to(torch.int8).cuda()
+    acc = F.conv2d(xi.double(), q.weight.double(), None, m.stride, m.padding, m.dilation, m.groups).to(torch.int32)
+    ref = OC.epilogue_f32(acc.cpu().numpy(), q.bias.cpu().numpy(), q.scalers.cpu().numpy(), 3.0)
+    y = q(xi)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref)
