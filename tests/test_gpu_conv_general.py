@@ -204,3 +204,38 @@ def test_weight_activation_layer_forward(kw):
     ref = OC.epilogue_f32(acc.cpu().numpy(), q.bias.cpu().numpy(), q.scalers.cpu().numpy(), 3.0)
     y = q(xi)
     np.testing.assert_array_equal(y.cpu().numpy(), ref)
+
+
+def test_chunker_on_a_mobile_style_model():
+    """Chunker(model).model, then a forward (the reference's flow, quant/Weight_Only/Main.py:40-42, Chunker.py:10-15), on a
+    model whose convolutions are strided, depthwise, pointwise, dilated and 'same'-padded: the output equals the same network
+    evaluated layer by layer as the reference's forward writes it, scale * (F.conv2d(x, Wq) + b) in float64, within 1e-3."""
+    from quantization_amd.qlayers import WeightOnlyChunker, WeightOnlyQuantizer
+    torch.manual_seed(21)
+    net = nn.Sequential(
+        nn.Conv2d(3, 16, 3, stride=2, padding=1), nn.ReLU(),
+        nn.Conv2d(16, 16, 3, padding=1, groups=16), nn.ReLU(),
+        nn.Conv2d(16, 32, 1), nn.ReLU(),
+        nn.Conv2d(32, 32, 3, padding=2, dilation=2), nn.ReLU(),
+        nn.Conv2d(32, 32, (3, 5), stride=(2, 1), padding=(1, 2), groups=4), nn.ReLU(),
+        nn.Conv2d(32, 24, 4, padding="same"), nn.ReLU(),
+        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(24, 10)).cuda()
+    qnet = WeightOnlyChunker(net, None).model
+    layers = [m for m in qnet if isinstance(m, WeightOnlyQuantizer)]
+    assert len(layers) == 7 and sum(m.cnn for m in layers) == 6
+    x = torch.randn(5, 3, 40, 36, device="cuda")
+    y = qnet(x)
+    h = x.double()
+    for m in qnet:
+        if isinstance(m, WeightOnlyQuantizer):
+            s = m.weight_quant.scales.reshape(-1).double()
+            b = 0.0 if m.bias is None else m.bias.detach().double()
+            if m.cnn:
+                h = (F.conv2d(h, m.weight.double(), None, m.stride, m.padding, m.dilation, m.groups) +
+                     (b.view(1, -1, 1, 1) if m.bias is not None else 0.0)) * s.view(1, -1, 1, 1)
+            else:
+                h = (F.linear(h, m.weight.double()) + b) * s
+        else:
+            h = m(h)
+    assert y.shape == h.shape
+    np.testing.assert_allclose(y.cpu().numpy(), h.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(h.abs().max()))
