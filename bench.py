@@ -133,7 +133,8 @@ def weight_only_float(N_, dev):
     alpha = torch.rand(Nn, device=dev) * 0.01
     res = {"weight": f"int8 [{Nn},{K}], 10 copies in turn", "out_dtype": "float32",
            "timing": "HIP graph of 40 calls, replayed (call_ms); call by call from Python beside it"}
-    for M, dt in ((16, torch.bfloat16), (16, torch.float32), (256, torch.bfloat16), (256, torch.float32)):
+    for M, dt in ((16, torch.bfloat16), (16, torch.float16), (16, torch.float32), (256, torch.bfloat16), (256, torch.float16),
+                  (256, torch.float32)):
         x = torch.randn(M, K, device=dev).to(dt)
         out = torch.empty(M, Nn, device=dev)
         it = [0]

@@ -144,10 +144,11 @@ int miq_gemm_i8_noalloc(const int8_t* A, const int8_t* W, int w_layout, int64_t 
  * `weight.to(x.dtype)` on every call, F.linear, `+ bias`, and Qop.dequantize (Qop.py:164-181) with
  * alpha = scale, beta = 0 (zero_point is 0 for the symmetric int8 weights Qop.quantize produces).
  * The int8 weight is read as it is stored (one byte per element) and widened in registers; the
- * product runs on the bf16 MFMA with fp32 accumulation.  fp32 and fp16 activations are carried as
- * two bf16 planes (hi + lo), which keeps |x - hi - lo| below 2^-17 |x| (fp16: exact), so the result
- * agrees with the reference's fp32 product far inside 1e-3 relative; bf16 activations are used as
- * they are.  The epilogue is evaluated in fp32 with one rounding per step.
+ * product runs on the bf16 (fp16 activations: the fp16) MFMA with fp32 accumulation.  fp32 activations
+ * are carried as two bf16 planes (hi + lo), which keeps |x - hi - lo| below 2^-17 |x|, so the result
+ * agrees with the reference's fp32 product far inside 1e-3 relative; bf16 and fp16 activations are
+ * used as they are (every product exact in the accumulator).  The epilogue is evaluated in fp32 with
+ * one rounding per step.
  * x: [M,K] row-major of x_dtype MIQ_F32 | MIQ_F16 | MIQ_BF16.  W: int8 [N,K].  bias: fp32 [N] or NULL.
  * alpha: fp32 [N].  out: [M,N] of out_dtype MIQ_F32 | MIQ_BF16.
  * workspace: at least miq_gemm_w8_workspace(...) bytes, 256-byte aligned (the bf16 planes of x and,

@@ -131,6 +131,49 @@ __device__ __forceinline__ v8bf int8x8_to_bf16(int a, int b) {
     return __builtin_bit_cast(v8bf, uint4{p[0], p[1], p[2], p[3]});
 }
 
+// Eight int8 (two dwords) -> eight fp16, exact: the byte b ^ 0x80 under the exponent byte 0x64 is the fp16 number
+// 1024 + (b + 128), from which 1152 is subtracted two at a time.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v8h int8x8_to_f16(int a, int b) {
+    uint32_t p[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t v = static_cast<uint32_t>(i ? b : a) ^ 0x80808080u;
+        const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, v, 0x05010400u);   // b0 64 b1 64
+        const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, v, 0x07030602u);   // b2 64 b3 64
+        const v2h bias{static_cast<_Float16>(1152.0f), static_cast<_Float16>(1152.0f)};
+        p[2 * i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, lo) - bias);
+        p[2 * i + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, hi) - bias);
+    }
+    return __builtin_bit_cast(v8h, uint4{p[0], p[1], p[2], p[3]});
+}
+
+// The MFMA operand type of the weight-only GEMM kernels: bf16 (bf16 activations, or the hi / lo planes of fp32 ones), or fp16
+// for fp16 activations, which then need no planes: fp16 x int8 products are exact in the fp32 accumulator either way.
+template <bool F16>
+struct W8Frag {
+    using type = v8bf;
+};
+template <>
+struct W8Frag<true> {
+    using type = v8h;
+};
+template <bool F16>
+__device__ __forceinline__ typename W8Frag<F16>::type int8x8_to_frag(int a, int b) {
+    if constexpr (F16)
+        return int8x8_to_f16(a, b);
+    else
+        return int8x8_to_bf16(a, b);
+}
+template <bool F16, typename F>
+__device__ __forceinline__ v4f mfma_w8(F w, F x, v4f c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float dequant1f(float acc, float bias, float alpha, float beta) {
     return __fadd_rn(__fmul_rn(__fadd_rn(acc, bias), alpha), beta);
 }
@@ -138,8 +181,9 @@ __device__ __forceinline__ float dequant1f(float acc, float bias, float alpha, f
 // STAGES = 2: double buffer, one __syncthreads per K-tile.  STAGES > 2: ring of K-tile buffers with
 // STAGES-1 tiles in flight behind a counted vmcnt and one raw barrier per K-tile (the thin problems,
 // whose K-tile of MFMAs is far shorter than a fetch).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES, bool CONV = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int STAGES, bool CONV = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArgs g) {
+    using frag_t = typename W8Frag<F16>::type;
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -234,26 +278,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
         const char* wt = cur + XBYTES + wn * WN * kTileK;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            v8bf wf[2][FN];
+            frag_t wf[2][FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const v4i raw = lds_read16(wt + j * 16 * kTileK + wlo[h]);
-                wf[0][j] = int8x8_to_bf16(raw[0], raw[1]);
-                wf[1][j] = int8x8_to_bf16(raw[2], raw[3]);
+                wf[0][j] = int8x8_to_frag<F16>(raw[0], raw[1]);
+                wf[1][j] = int8x8_to_frag<F16>(raw[2], raw[3]);
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const char* xt = cur + (p * 2 + h) * XSUB + wm * WM * kTileK;
-                    v8bf xf[FM];
+                    frag_t xf[FM];
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) xf[i] = __builtin_bit_cast(v8bf, lds_read16(xt + i * 16 * kTileK + xlo[e]));
+                    for (int i = 0; i < FM; ++i) xf[i] = __builtin_bit_cast(frag_t, lds_read16(xt + i * 16 * kTileK + xlo[e]));
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], xf[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_w8<F16>(wf[e][j], xf[i], acc[i][j]);
                 }
         }
     };
@@ -385,8 +429,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_w8f_kernel(W8fArg
     } while (0)
 #define MIQ_W8F_WAIT_DMA() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 
-template <int OUT, int NP, int SCHED = 1>
+template <int OUT, int NP, int SCHED = 1, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
+    using frag_t = typename W8Frag<F16>::type;
     constexpr int kXHalf = 128 * kTileK;            // 128 rows x 64 bf16
     constexpr int kWHalf = 64 * kTileK;             // 128 rows x 64 int8 = 64 row pairs
     constexpr int kBuf = 2 * kXHalf + 2 * kWHalf;   // X0 X1 W0 W1
@@ -470,22 +515,22 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
     MIQ_W8F_BARRIER();
     if (wm == 1) MIQ_W8F_BARRIER();
 
-    v8bf xf[2][4], xf2[2][4], wf0[2][2], wf1[2][2];   // [k half][fragment]
-    auto read_w = [&](v8bf (&wf)[2][2], const char* half) {
+    frag_t xf[2][4], xf2[2][4], wf0[2][2], wf1[2][2];   // [k half][fragment]
+    auto read_w = [&](frag_t (&wf)[2][2], const char* half) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const v4i raw = lds_read16(half + w_frag + j * 8 * kTileK + wlo);
-            wf[0][j] = int8x8_to_bf16(raw[0], raw[1]);
-            wf[1][j] = int8x8_to_bf16(raw[2], raw[3]);
+            wf[0][j] = int8x8_to_frag<F16>(raw[0], raw[1]);
+            wf[1][j] = int8x8_to_frag<F16>(raw[2], raw[3]);
         }
     };
-    auto read_x = [&](v8bf (&f)[2][4], const char* half) {
+    auto read_x = [&](frag_t (&f)[2][4], const char* half) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[e][i] = __builtin_bit_cast(v8bf, lds_read16(half + x_frag + i * 16 * kTileK + xlo[e]));
+            for (int i = 0; i < 4; ++i) f[e][i] = __builtin_bit_cast(frag_t, lds_read16(half + x_frag + i * 16 * kTileK + xlo[e]));
     };
-    auto mma = [&](v4f (&c)[4][2], const v8bf (&f)[2][4], const v8bf (&wf)[2][2]) {
+    auto mma = [&](v4f (&c)[4][2], const frag_t (&f)[2][4], const frag_t (&wf)[2][2]) {
         if constexpr (SCHED == 0) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -493,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+                        c[i][j] = mfma_w8<F16>(wf[e][j], f[e][i], c[i][j]);
         } else {
             // the two k-halves of an accumulator back to back, the weight fragment alternating 0 1 1 0 (pinned with
             // scheduling barriers: left alone the compiler restores the k-major order)
@@ -504,7 +549,7 @@ __global__ __launch_bounds__(512) void gemm_w8f_256_kernel(W8fArgs g) {
                     const int j = (i & 1) ? 1 - jj : jj;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[e][j], f[e][i], c[i][j], 0, 0, 0);
+                        c[i][j] = mfma_w8<F16>(wf[e][j], f[e][i], c[i][j]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -717,7 +762,7 @@ W8fPlan plan_w8f(int64_t M, int64_t N, int64_t K, int planes) {
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, int OUT, bool F16 = false>
 int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st) {
     constexpr int STAGES = w8f_stages(BM, BN, NP);
     static_assert(STAGES >= 2, "a tile needs two K-tile buffers");
@@ -730,7 +775,7 @@ int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st
         W8fArgs part = g;
         part.out = slabs;
         part.kt_per_split = plan.kt_per_split;
-        auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, kOutRaw, STAGES>;
+        auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, kOutRaw, STAGES, false, F16>;
         if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
         kern<<<dim3(static_cast<unsigned>(nwg), static_cast<unsigned>(plan.splits)), 64 * WAVES_M * WAVES_N, kLds, st>>>(part);
         if (int rc = check_launch("gemm_w8f_kernel (split-K)")) return rc;
@@ -739,24 +784,24 @@ int launch_w8f_tile(W8fArgs g, const W8fPlan& plan, float* slabs, hipStream_t st
         w8f_splitk_reduce_kernel<OUT><<<rgrid, 256, 0, st>>>(slabs, plan.splits, g);
         return check_launch("w8f_splitk_reduce_kernel");
     }
-    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES>;
+    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES, false, F16>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
     return check_launch("gemm_w8f_kernel");
 }
 
-template <int NP, int OUT>
+template <int NP, int OUT, bool F16 = false>
 int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t st) {
     switch (plan.bm * 1000 + plan.bn) {
-        case 16064: return launch_w8f_tile<16, 64, 1, 4, NP, OUT>(g, plan, slabs, st);
-        case 16128: return launch_w8f_tile<16, 128, 1, 4, NP, OUT>(g, plan, slabs, st);
-        case 16256: return launch_w8f_tile<16, 256, 1, 4, NP, OUT>(g, plan, slabs, st);
-        case 32064: return launch_w8f_tile<32, 64, 1, 4, NP, OUT>(g, plan, slabs, st);
-        case 32128: return launch_w8f_tile<32, 128, 1, 4, NP, OUT>(g, plan, slabs, st);
-        case 32256: return launch_w8f_tile<32, 256, 1, 8, NP, OUT>(g, plan, slabs, st);
-        case 64064: return launch_w8f_tile<64, 64, 2, 2, NP, OUT>(g, plan, slabs, st);
-        case 64128: return launch_w8f_tile<64, 128, 2, 2, NP, OUT>(g, plan, slabs, st);
-        case 64256: return launch_w8f_tile<64, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
+        case 16064: return launch_w8f_tile<16, 64, 1, 4, NP, OUT, F16>(g, plan, slabs, st);
+        case 16128: return launch_w8f_tile<16, 128, 1, 4, NP, OUT, F16>(g, plan, slabs, st);
+        case 16256: return launch_w8f_tile<16, 256, 1, 4, NP, OUT, F16>(g, plan, slabs, st);
+        case 32064: return launch_w8f_tile<32, 64, 1, 4, NP, OUT, F16>(g, plan, slabs, st);
+        case 32128: return launch_w8f_tile<32, 128, 1, 4, NP, OUT, F16>(g, plan, slabs, st);
+        case 32256: return launch_w8f_tile<32, 256, 1, 8, NP, OUT, F16>(g, plan, slabs, st);
+        case 64064: return launch_w8f_tile<64, 64, 2, 2, NP, OUT, F16>(g, plan, slabs, st);
+        case 64128: return launch_w8f_tile<64, 128, 2, 2, NP, OUT, F16>(g, plan, slabs, st);
+        case 64256: return launch_w8f_tile<64, 256, 2, 4, NP, OUT, F16>(g, plan, slabs, st);
         default: break;
     }
     if (plan.bm == 256 && plan.bn == 256) {
@@ -764,19 +809,19 @@ int launch_w8f(const W8fArgs& g, const W8fPlan& plan, float* slabs, hipStream_t 
         a.tiles_m = static_cast<int>(ceil_div(g.M, 256));
         a.tiles_n = static_cast<int>(ceil_div(g.N, 256));
         constexpr int kLds = 2 * (2 * 128 + 2 * 64) * kTileK;
-        auto kern = gemm_w8f_256_kernel<OUT, NP>;
+        auto kern = gemm_w8f_256_kernel<OUT, NP, 1, F16>;
 #ifndef MIQ_NO_DEV_SWITCHES
         if (const char* sc = dev_switch("MIQ_W8F_SCHED"))   // developer A/B switch: 0 = the four-phase schedule
-            if (sc[0] == '0') kern = gemm_w8f_256_kernel<OUT, NP, 0>;
+            if (sc[0] == '0') kern = gemm_w8f_256_kernel<OUT, NP, 0, F16>;
 #endif
         if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
         kern<<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
         return check_launch("gemm_w8f_256_kernel");
     }
     if constexpr (NP == 1) {   // one activation plane leaves LDS for wider tiles
-        if (plan.bm == 128 && plan.bn == 256) return launch_w8f_tile<128, 256, 2, 4, NP, OUT>(g, plan, slabs, st);
+        if (plan.bm == 128 && plan.bn == 256) return launch_w8f_tile<128, 256, 2, 4, NP, OUT, F16>(g, plan, slabs, st);
     }
-    return launch_w8f_tile<128, 128, 2, 4, NP, OUT>(g, plan, slabs, st);
+    return launch_w8f_tile<128, 128, 2, 4, NP, OUT, F16>(g, plan, slabs, st);
 }
 
 template <typename T, int OUT>
@@ -1051,7 +1096,7 @@ int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
 }
 
 size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
-    return x_dtype == MIQ_BF16 ? 0 : static_cast<size_t>(round_up(M * K * 2, 256));
+    return x_dtype == MIQ_F32 ? static_cast<size_t>(round_up(M * K * 2, 256)) : 0;   // bf16 and fp16 activations are used as they are
 }
 // As for the int8 GEMM: a count of 256 x 256 tiles a little over whole rounds of the 256 CUs is cut along M into
 // the whole rounds (pipelined kernel) and a small second problem.  Returns the rows of the first part, or M.
@@ -1798,7 +1843,7 @@ int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w
 
 extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return 0;
-    return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K, x_dtype == MIQ_BF16 ? 1 : 2);
+    return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K, x_dtype == MIQ_F32 ? 2 : 1);
 }
 
 extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
@@ -1844,18 +1889,15 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
         MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_w8: workspace must be 256-byte aligned");
     }
     const size_t pb = plane_bytes(x_dtype, M, K);
-    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    const int planes = x_dtype == MIQ_F32 ? 2 : 1;   // fp16 activations go to the fp16 MFMA as they are, bf16 ones to the bf16 MFMA
     float* slabs = w8f_slab_bytes(M, N, K, planes) ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * pb) : nullptr;
     const W8fPlan plan = plan_w8f(M, N, K, planes);
-    if (x_dtype != MIQ_BF16) {
+    if (x_dtype == MIQ_F32) {
         uint16_t* hi = static_cast<uint16_t*>(workspace);
         uint16_t* lo = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + pb);
         const int64_t groups = M * K / 8;
         const int grid = static_cast<int>(groups / 256 + 1 < 8192 ? groups / 256 + 1 : 8192);
-        if (x_dtype == MIQ_F32)
-            split_planes_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float*>(x), hi, lo, groups);
-        else
-            split_planes_kernel<_Float16><<<grid, 256, 0, st>>>(static_cast<const _Float16*>(x), hi, lo, groups);
+        split_planes_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float*>(x), hi, lo, groups);
         if (int rc = check_launch("split_planes_kernel")) return rc;
         g.X = hi;
         g.plane_stride = static_cast<uint32_t>(pb);
@@ -1863,6 +1905,8 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
     auto run = [&](const W8fArgs& part, const W8fPlan& pl) {
         if (planes == 2)
             return out_dtype == MIQ_F32 ? launch_w8f<2, kOutF32>(part, pl, slabs, st) : launch_w8f<2, kOutBF16>(part, pl, slabs, st);
+        if (x_dtype == MIQ_F16)
+            return out_dtype == MIQ_F32 ? launch_w8f<1, kOutF32, true>(part, pl, slabs, st) : launch_w8f<1, kOutBF16, true>(part, pl, slabs, st);
         return out_dtype == MIQ_F32 ? launch_w8f<1, kOutF32>(part, pl, slabs, st) : launch_w8f<1, kOutBF16>(part, pl, slabs, st);
     };
     const int64_t m_main = w8f_rows_in_whole_rounds(M, N, K, planes);

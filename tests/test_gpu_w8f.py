@@ -254,7 +254,7 @@ def test_w8f_random_shapes(N):
               out_dtype=torch.bfloat16 if rnd.random() < 0.25 else torch.float32)
 
 
-@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+@pytest.mark.parametrize("xdt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("M,Nn,K", [(8192, 8192, 8192), (256, 14336, 4096), (16, 4096, 14336)])
 def test_w8f_full_size_equals_the_int8_product(N, M, Nn, K, xdt):
     """Full BASELINE sizes, every element: on small integer activations (|x| <= 8, so every partial sum stays below
@@ -270,7 +270,7 @@ def test_w8f_full_size_equals_the_int8_product(N, M, Nn, K, xdt):
     assert torch.equal(y, ref)
 
 
-@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+@pytest.mark.parametrize("xdt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("M,Nn,K", [(2304, 8192, 80), (2100, 8192, 144), (4400, 8190, 64)])
 def test_w8f_whole_rounds_plus_tail(N, M, Nn, K, xdt):
     """A count of 256 x 256 tiles a little over whole rounds of the CUs runs as the whole rounds plus a second launch

@@ -33,7 +33,7 @@ def timed(fn):
 
 CASES = [(m, 14336, 4096) for m in (1, 16, 32, 64, 128, 256)] + [(m, 4096, 14336) for m in (1, 16, 64, 256)] + \
         [(2048, 14336, 4096), (8192, 8192, 8192)]
-for dt in (torch.float32, torch.bfloat16):
+for dt in (torch.float32, torch.bfloat16, torch.float16):
     if only and only not in str(dt):
         continue
     for M, Nn, K in CASES:
