@@ -149,6 +149,37 @@ __device__ __forceinline__ v8h int8x8_to_f16(int a, int b) {
     return __builtin_bit_cast(v8h, uint4{p[0], p[1], p[2], p[3]});
 }
 
+__device__ __forceinline__ uint32_t pack2_f16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, v2h{static_cast<_Float16>(a), static_cast<_Float16>(b)});
+}
+// fp16 activations carried as ONE plane keep their own format (T = _Float16, NP = 1); every other plane is bf16.
+template <typename T, int NP>
+constexpr bool kPlaneF16 = std::is_same_v<T, _Float16> && NP == 1;
+
+// Two activations -> their packed 16-bit forms: the plane's own (bf16, or fp16 as it is) and, for two planes, the bf16 rest.
+template <typename T, int NP>
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+    if constexpr (kPlaneF16<T, NP>) {
+        hi = pack2_f16(v0, v1);
+        lo = 0u;
+    } else {
+        float fh[2], fl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = e ? v1 : v0;
+            fh[e] = bf16_round(v);
+            fl[e] = 0.0f;
+            if constexpr (NP == 2) {
+                if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
+                    fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+                fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
+            }
+        }
+        hi = pack2_bf16(fh[0], fh[1]);
+        lo = pack2_bf16(fl[0], fl[1]);
+    }
+}
+
 // The MFMA operand type of the weight-only GEMM kernels: bf16 (bf16 activations, or the hi / lo planes of fp32 ones), or fp16
 // for fp16 activations, which then need no planes: fp16 x int8 products are exact in the fp32 accumulator either way.
 template <bool F16>
@@ -983,19 +1014,7 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_kernel(const T* __restrict
         if (p >= HW || c0 + cg * 8 >= Cp) continue;
         uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float fh[2], fl[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float v = tile[cg * 8 + 2 * j + e][pixl];
-                fh[e] = bf16_round(v);
-                if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))
-                    fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
-                fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
-            }
-            hi[j] = pack2_bf16(fh[0], fh[1]);
-            lo[j] = pack2_bf16(fl[0], fl[1]);
-        }
+        for (int j = 0; j < 4; ++j) split2<T, NP>(tile[cg * 8 + 2 * j][pixl], tile[cg * 8 + 2 * j + 1][pixl], hi[j], lo[j]);
         const int h = p / W, w = p - h * W;
         uint16_t* o = xp + ((static_cast<size_t>(b) * Hp + h + pad) * Wp + w + pad) * Cp + c0 + cg * 8;
         *reinterpret_cast<uint4*>(o) = uint4{hi[0], hi[1], hi[2], hi[3]};
@@ -1022,19 +1041,7 @@ __global__ __launch_bounds__(256) void conv_w8_prep_x_small_kernel(const T* __re
                 f[j] = c < Cin ? to_f32(x[((static_cast<size_t>(b) * Cin + c) * Hs + h * sub) * Ws + w * sub]) : 0.0f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float fh[2], fl[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float v = f[2 * j + e];
-                    fh[e] = bf16_round(v);
-                    if (__builtin_isinf(fh[e]) && !__builtin_isinf(v))
-                        fh[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
-                    fl[e] = (__builtin_isinf(fh[e]) || fh[e] != fh[e]) ? 0.0f : __fsub_rn(v, fh[e]);
-                }
-                hi[j] = pack2_bf16(fh[0], fh[1]);
-                lo[j] = pack2_bf16(fl[0], fl[1]);
-            }
+            for (int j = 0; j < 4; ++j) split2<T, NP>(f[2 * j], f[2 * j + 1], hi[j], lo[j]);
         }
         uint16_t* o = xp + static_cast<size_t>(ppix) * Cp + cg * 8;
         *reinterpret_cast<uint4*>(o) = uint4{hi[0], hi[1], hi[2], hi[3]};
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(256) void conv_w8_pack_w_kernel(const int8_t* __res
     conv_w8_pack_w_items(w, wp, total, Cin, KH, KW, Cp, L, Lp, blockIdx.x * 256u + threadIdx.x, 256u * gridDim.x);
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int DEPTH = 0, int BM = 128>
+template <int BN, int WAVES_M, int WAVES_N, int NP, int OUT, int DEPTH = 0, int BM = 128, bool F16 = false>
 int launch_conv_w8f(W8fArgs g, hipStream_t st) {
     constexpr int STAGES = DEPTH ? DEPTH : w8f_stages(BM, BN, NP);
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
@@ -1055,17 +1062,17 @@ int launch_conv_w8f(W8fArgs g, hipStream_t st) {
     constexpr int kLds = STAGES * (NP * 2 * BM + BN) * kTileK;
     const int64_t nwg = static_cast<int64_t>(g.tiles_m) * g.tiles_n;
     if (nwg >= (1ll << 31)) return fail(MIQ_ERANGE, "miq_conv2d_w8: too many tiles");
-    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES, true>;
+    auto kern = gemm_w8f_kernel<BM, BN, WAVES_M, WAVES_N, NP, OUT, STAGES, true, F16>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     kern<<<static_cast<int>(nwg), 64 * WAVES_M * WAVES_N, kLds, st>>>(g);
     return check_launch("gemm_w8f_kernel (convolution)");
 }
 
-template <int NP, int OUT>
+template <int NP, int OUT, bool F16 = false>
 int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
     // 64-channel tiles up to 64 output channels (no empty tile columns), 128-channel tiles beyond
     const char* d = dev_switch("MIQ_CONV_W8_TILE");   // developer A/B switch
-    if (d) {
+    if (d && !F16) {
         switch (d[0]) {
             case 'a': return launch_conv_w8f<64, 2, 2, NP, OUT, 2>(g, st);            // 128 x 64, double-buffered
             case 'b': return launch_conv_w8f<128, 2, 4, NP, OUT, 2>(g, st);           // 128 x 128, double-buffered
@@ -1083,16 +1090,16 @@ int launch_conv_w8f_np(const W8fArgs& g, hipStream_t st) {
     // (80 KiB of LDS each) hide each other's fetches better than one with a deeper ring: 128 x 64 tiles for one plane
     // (239 against 354 us on 64->64 56x56 at batch 256), 64 x 64 for two (361 against 478 us).
     if (g.N <= 64) {
-        if constexpr (NP == 1) return launch_conv_w8f<64, 2, 2, NP, OUT, 2>(g, st);
+        if constexpr (NP == 1) return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 128, F16>(g, st);
         return launch_conv_w8f<64, 2, 2, NP, OUT, 2, 64>(g, st);
     }
     // One plane and more than 128 output channels: 128 x 256 tiles halve the passes over the expanded activations,
     // which is what bounds these layers (ResNet-18 at batch 256, bf16: 256->256 14x14 128 -> 112 us, 512->512 7x7
     // 113 -> 99 us, 128->256 3x3/2 89 -> 77 us), once there are tiles for most CUs.  Two planes would need 192 KiB.
     if constexpr (NP == 1) {
-        if (g.N > 128 && ceil_div(g.M, 128) * ceil_div(g.N, 256) >= 160) return launch_conv_w8f<256, 2, 4, NP, OUT, 2>(g, st);
+        if (g.N > 128 && ceil_div(g.M, 128) * ceil_div(g.N, 256) >= 160) return launch_conv_w8f<256, 2, 4, NP, OUT, 2, 128, F16>(g, st);
     }
-    return launch_conv_w8f<128, 2, 4, NP, OUT>(g, st);
+    return launch_conv_w8f<128, 2, 4, NP, OUT, 0, 128, F16>(g, st);
 }
 
 size_t plane_bytes(int x_dtype, int64_t M, int64_t K) {
@@ -1174,22 +1181,11 @@ __device__ __forceinline__ void patch_w8_prep_items(const T* __restrict__ x, uin
         if (h >= 0 && h < H && w >= 0 && w < W) {
             const T* src = x + ((static_cast<size_t>(b) * Cin + c8 * 8) * H + h) * W + w;
             const size_t cs = static_cast<size_t>(H) * W;
-            float fh[8], fl[8];
+            float f[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = to_f32(src[j * cs]);
-                fh[j] = bf16_round(v);
-                if constexpr (NP == 2) {
-                    if (__builtin_isinf(fh[j]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
-                        fh[j] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
-                    fl[j] = (__builtin_isinf(fh[j]) || fh[j] != fh[j]) ? 0.0f : __fsub_rn(v, fh[j]);
-                }
-            }
+            for (int j = 0; j < 8; ++j) f[j] = to_f32(src[j * cs]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hi[j] = pack2_bf16(fh[2 * j], fh[2 * j + 1]);
-                if constexpr (NP == 2) lo[j] = pack2_bf16(fl[2 * j], fl[2 * j + 1]);
-            }
+            for (int j = 0; j < 4; ++j) split2<T, NP>(f[2 * j], f[2 * j + 1], hi[j], lo[j]);
         }
         // plane of the hi chunk: bf16: the octet itself; two planes: group c8 >> 1, k-group c8 & 1 (lo: + 2)
         const uint32_t plane = NP == 1 ? c8 : (c8 >> 1) * 4 + (c8 & 1);
@@ -1202,7 +1198,7 @@ __device__ __forceinline__ void patch_w8_prep_items(const T* __restrict__ x, uin
 // OIHW int8 (3 x 3) -> wp[Cout / 64][groups][tap][k-group][channel % 64][8 bf16]: per 64-output-channel tile and group
 // one contiguous image of the LDS weight stage (zero past Cout), already widened to bf16 (exact) so that the kernel's
 // taps carry no conversion.  One item per 16-byte chunk: eight consecutive input channels of one tap.
-template <int NP>
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void patch_w8_pack_items(const int8_t* __restrict__ w, uint4* __restrict__ wp, uint32_t total_chunks,
                                                     int Cin, int Cout, uint32_t first, uint32_t step) {
     constexpr uint32_t NQ = NP == 1 ? 4 : 2, CPG = NQ * 8;   // k-groups and channels of a group
@@ -1218,7 +1214,10 @@ __device__ __forceinline__ void patch_w8_pack_items(const int8_t* __restrict__ w
         if (n < static_cast<uint32_t>(Cout)) {
             const int8_t* src = w + (static_cast<size_t>(n) * Cin + c) * 9 + tap;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = pack2_bf16(static_cast<float>(src[(2 * j) * 9]), static_cast<float>(src[(2 * j + 1) * 9]));
+            for (int j = 0; j < 4; ++j) {
+                const float w0 = static_cast<float>(src[(2 * j) * 9]), w1 = static_cast<float>(src[(2 * j + 1) * 9]);
+                v[j] = F16 ? pack2_f16(w0, w1) : pack2_bf16(w0, w1);
+            }
         }
         wp[idx] = uint4{v[0], v[1], v[2], v[3]};
     }
@@ -1234,11 +1233,12 @@ __global__ __launch_bounds__(256) void patch_w8_prep_kernel(const T* __restrict_
     if (static_cast<int>(blockIdx.x) < n_prep)
         patch_w8_prep_items<T, NP>(x, xp, Cin, H, W, Hp, pitch, pad, ptot, total, blockIdx.x * 256u + threadIdx.x, 256u * n_prep);
     else
-        patch_w8_pack_items<NP>(w, wp, total_chunks, Cin, Cout, (blockIdx.x - n_prep) * 256u + threadIdx.x, 256u * n_pack);
+        patch_w8_pack_items<NP, kPlaneF16<T, NP>>(w, wp, total_chunks, Cin, Cout, (blockIdx.x - n_prep) * 256u + threadIdx.x, 256u * n_pack);
 }
 
-template <int OUT, int NP, bool STREAM>
+template <int OUT, int NP, bool STREAM, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g) {
+    using frag_t = typename W8Frag<F16>::type;   // fp16 activations as one plane: fp16 fragments (filters widened to fp16)
     constexpr int FM = 7, FN = 2;
     constexpr int NQ = NP == 1 ? 4 : 2;                  // k-groups of the weight stage
     constexpr int kWst = 9 * NQ * 64 * kChunk;           // bytes of one weight stage (bf16)
@@ -1417,15 +1417,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
             const char* patch = smem + buf * kPatch;
             const char* wst = smem + 2 * kPatch + (w_res ? cg : buf) * kWst + w_lane;
             {
-                v8bf af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
+                frag_t af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
                 auto read_tap = [&](auto S, int kh, int kw) {
                     constexpr int s = decltype(S)::value;
                     const char* arow = patch + (kh * g.pitch + kw) * kChunk;
                     const char* wrow = wst + (kh * 3 + kw) * (NQ * 64 * kChunk);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) wf[s][j] = __builtin_bit_cast(v8bf, lds_read16(wrow + j * 16 * kChunk));
+                    for (int j = 0; j < FN; ++j) wf[s][j] = __builtin_bit_cast(frag_t, lds_read16(wrow + j * 16 * kChunk));
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) af[s][i] = __builtin_bit_cast(v8bf, lds_read16(arow + aoff[i]));
+                    for (int i = 0; i < FM; ++i) af[s][i] = __builtin_bit_cast(frag_t, lds_read16(arow + aoff[i]));
                 };
                 auto tap = [&](auto T) {
                     constexpr int t = decltype(T)::value, s = t & 1;
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][i], wf[s][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_w8<F16>(af[s][i], wf[s][j], acc[i][j]);
                     // the finished unit's row t leaves behind this tap's MFMAs, as a block of its own behind a branch
                     __builtin_amdgcn_sched_barrier(0);
                     if (flush) stores += store_step(rout, prev, T);
@@ -1481,6 +1481,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
 
 // Geometry of the patch path, or ok = false when the layer does not take it: 3 x 3 / stride 1, whole 32-channel groups,
 // enough pixels for every CU, and a patch that fits the LDS planes.
+// Activation planes of the patch and im2col-order convolution kernels: fp32 as hi + lo bf16, bf16 and fp16 as they are.
+// (The stem kernel packs hi | lo of fp16 activations into one 16-byte pixel as it does for fp32.)
+inline int conv_w8_planes(int x_dtype) { return x_dtype == MIQ_F32 ? 2 : 1; }
+
 struct PatchW8Geom {
     bool ok;
     int64_t Hp, Wp, pitch, Ho, Wo, ptot, group, ncg;
@@ -1514,10 +1518,10 @@ PatchW8Geom make_patch_w8_geom(int planes, int64_t B, int64_t Cin, int64_t H, in
     return p;
 }
 
-template <int OUT, int NP>
+template <int OUT, int NP, bool F16 = false>
 int launch_patch_w8(const PatchW8Args& a, bool stream_out, hipStream_t st) {
-    void (*kern)(PatchW8Args) = conv3x3_patch_w8_kernel<OUT, NP, false>;
-    if (stream_out) kern = conv3x3_patch_w8_kernel<OUT, NP, true>;
+    void (*kern)(PatchW8Args) = conv3x3_patch_w8_kernel<OUT, NP, false, F16>;
+    if (stream_out) kern = conv3x3_patch_w8_kernel<OUT, NP, true, F16>;
     constexpr int kWst = 9 * (NP == 1 ? 4 : 2) * 64 * kChunk;
     static_assert(2 * kPatchW8Bytes + 2 * kWst <= 160 * 1024, "LDS of one CU");
     // two filter stages, or every group's filters when they fit (the kernel makes the same choice)
@@ -1534,7 +1538,7 @@ int launch_patch_w8(const PatchW8Args& a, bool stream_out, hipStream_t st) {
 int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
                  int64_t Cout, int64_t pad, const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                  void* workspace, hipStream_t st) {
-    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    const int planes = conv_w8_planes(x_dtype);
     uint16_t* xp = static_cast<uint16_t*>(workspace);
     uint4* wp = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
     const int64_t items = (Cin / 8) * P.ptot;   // one thread per channel octet and padded pixel
@@ -1549,7 +1553,7 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
     if (x_dtype == MIQ_F32)
         MIQ_PATCH_PREP(float, 2);
     else if (x_dtype == MIQ_F16)
-        MIQ_PATCH_PREP(_Float16, 2);
+        MIQ_PATCH_PREP(_Float16, 1);
     else
         MIQ_PATCH_PREP(__bf16, 1);
 #undef MIQ_PATCH_PREP
@@ -1566,9 +1570,10 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
     set_patch_units(a, B, P.Ho * P.Wo, P.Hp, P.pitch, P.group);
     const int64_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
     const bool stream_out = B * Cout * P.Ho * P.Wo * esz >= (192ll << 20) && out_dtype != MIQ_BF16;
-#define MIQ_PATCH_RUN(NP) \
-    (out_dtype == MIQ_F32 ? launch_patch_w8<kOutF32, NP>(a, stream_out, st) : launch_patch_w8<kOutBF16, NP>(a, false, st))
-    return planes == 1 ? MIQ_PATCH_RUN(1) : MIQ_PATCH_RUN(2);
+#define MIQ_PATCH_RUN(NP, F16) \
+    (out_dtype == MIQ_F32 ? launch_patch_w8<kOutF32, NP, F16>(a, stream_out, st) : launch_patch_w8<kOutBF16, NP, F16>(a, false, st))
+    if (x_dtype == MIQ_F16) return MIQ_PATCH_RUN(1, true);
+    return planes == 1 ? MIQ_PATCH_RUN(1, false) : MIQ_PATCH_RUN(2, false);
 #undef MIQ_PATCH_RUN
 }
 
@@ -1971,7 +1976,7 @@ static int conv_w8_relayout(const void* x, int x_dtype, const int8_t* w, uint16_
     if (x_dtype == MIQ_F32)
         MIQ_PREP(float, 2);
     else if (x_dtype == MIQ_F16)
-        MIQ_PREP(_Float16, 2);
+        MIQ_PREP(_Float16, 1);
     else
         MIQ_PREP(__bf16, 1);
 #undef MIQ_PREP
@@ -1988,11 +1993,11 @@ extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, i
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvW8Geom G;
     if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
-    const PatchW8Geom P = make_patch_w8_geom(x_dtype == MIQ_BF16 ? 1 : 2, B, Cin, H, W, Cout, KH, KW, stride, pad);
+    const PatchW8Geom P = make_patch_w8_geom(conv_w8_planes(x_dtype), B, Cin, H, W, Cout, KH, KW, stride, pad);
     if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256) + round_up(P.wp_bytes, 256));
     const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
     if (S.ok) return static_cast<size_t>(round_up(S.xp_bytes, 256) + round_up(S.wp_bytes, 256));
-    return static_cast<size_t>((x_dtype == MIQ_BF16 ? 1 : 2) * G.plane_bytes + G.wp_bytes);
+    return static_cast<size_t>(conv_w8_planes(x_dtype) * G.plane_bytes + G.wp_bytes);
 }
 
 extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
@@ -2010,7 +2015,7 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
                 "miq_conv2d_w8: out_dtype must be MIQ_F32 or MIQ_BF16 (got %d)", out_dtype);
     if (G.M == 0 || Cout == 0) return MIQ_OK;
     MIQ_REQUIRE(x && w && out && alpha, MIQ_EINVAL, "miq_conv2d_w8: null pointer");
-    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    const int planes = conv_w8_planes(x_dtype);
     MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
                 MIQ_ERANGE, "miq_conv2d_w8: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
                 (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
@@ -2053,6 +2058,8 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
               static_cast<uint32_t>(G.Hp * G.Wp * G.Cp * 2),
               static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Lp)) + 1u};
     if (planes == 2) return out_dtype == MIQ_F32 ? launch_conv_w8f_np<2, kOutF32>(g, st) : launch_conv_w8f_np<2, kOutBF16>(g, st);
+    if (x_dtype == MIQ_F16)
+        return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32, true>(g, st) : launch_conv_w8f_np<1, kOutBF16, true>(g, st);
     return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
 }
 
@@ -2101,7 +2108,7 @@ size_t conv2d_w8_dense_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H,
         Cout == 0)
         return 0;
     // (0 as well for what the kernel's 32-bit offsets do not reach: the caller then takes the direct convolution)
-    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    const int planes = conv_w8_planes(x_dtype);
     if (planes * G.plane_bytes >= (1ll << 31) || Cout * G.K >= (1ll << 31) || G.M >= (1ll << 31) || G.K * G.Lp >= (1ll << 31) ||
         B * (ceil_div(H * W, 64) * ceil_div(G.Cp, 64) + 8192) >= (1ll << 31))
         return 0;
@@ -2118,7 +2125,7 @@ int conv2d_w8_dense(const void* x, int x_dtype, const int8_t* w, int64_t B, int6
     MIQ_REQUIRE(make_conv_w8_dense_geom(B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw, G, P, rows, kw_run), MIQ_EINVAL,
                 "miq_conv2d_general: bad geometry");
     if (G.M == 0 || Cout == 0) return MIQ_OK;
-    const int planes = x_dtype == MIQ_BF16 ? 1 : 2;
+    const int planes = conv_w8_planes(x_dtype);
     MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
                 MIQ_ERANGE, "miq_conv2d_general: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
                 (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
@@ -2145,6 +2152,8 @@ int conv2d_w8_dense(const void* x, int x_dtype, const int8_t* w, int64_t B, int6
         g.tap_bytes = static_cast<uint32_t>(dw * G.Cp * 2);
     }
     if (planes == 2) return out_dtype == MIQ_F32 ? launch_conv_w8f_np<2, kOutF32>(g, st) : launch_conv_w8f_np<2, kOutBF16>(g, st);
+    if (x_dtype == MIQ_F16)
+        return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32, true>(g, st) : launch_conv_w8f_np<1, kOutBF16, true>(g, st);
     return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
 }
 

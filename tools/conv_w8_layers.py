@@ -13,7 +13,7 @@ from quantization_amd import _native as N  # noqa: E402
 
 B, dev = 256, torch.device("cuda", 0)
 tot = {}
-for dt in (torch.float32, torch.bfloat16):
+for dt in (torch.float32, torch.bfloat16, torch.float16):
     tot[dt] = 0.0
     for C, H, Co, k, s, p, times in bench.RESNET18_CONVS:
         x = torch.randn(B, C, H, H, device=dev).to(dt)
