@@ -301,7 +301,7 @@ def conv_weight_only_float(N_, dev):
     planes of fp32 activations are twice that in MFMA work); roofline against the dense bf16 MFMA peak."""
     B = 256
     res = {"batch": B, "out_dtype": "float32", "timing": "per layer a HIP graph of 6 calls, replayed"}
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
         total_ms, total_ops = 0.0, 0.0
         for C, H, Co, k, s, p, times in RESNET18_CONVS:
             x = torch.randn(B, C, H, H, device=dev).to(dt)
