@@ -239,3 +239,22 @@ def test_chunker_on_a_mobile_style_model():
             h = m(h)
     assert y.shape == h.shape
     np.testing.assert_allclose(y.cpu().numpy(), h.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(h.abs().max()))
+
+
+def test_dense_layer_into_an_output_that_is_not_vector_aligned(N):
+    """A dense layer whose output starts one element into its buffer cannot take the MFMA kernels' vector stores: the direct
+    kernel computes it (same exact sums; the same fp32 epilogue)."""
+    B, C, H, W, Co = 2, 24, 13, 14, 40
+    x, w = rand_i8((B, C, H, W), 3).cuda(), rand_i8((Co, C, 3, 3), 4).cuda()
+    ref = F.conv2d(x.double(), w.double(), stride=(1, 2), padding=(2, 1), dilation=(2, 1)).to(torch.int32)
+    flat = torch.zeros(ref.numel() + 4, dtype=torch.int32, device="cuda")
+    out = flat[1:1 + ref.numel()].view(ref.shape)
+    assert out.data_ptr() % 16 == 4
+    N.conv2d_general(x, w, (1, 2), (2, 1), (2, 1), 1, out_dtype=torch.int32, out=out)
+    assert torch.equal(out, ref) and int(flat[0]) == 0 and int(flat[-1]) == 0
+    alpha = torch.rand(Co, device="cuda") * 0.01
+    yf = torch.zeros(ref.numel() + 4, device="cuda")
+    y = yf[1:1 + ref.numel()].view(ref.shape)
+    N.conv2d_general(x.float(), w, (1, 2), (2, 1), (2, 1), 1, alpha=alpha, out=y)
+    want = ref.double() * alpha.double().view(1, -1, 1, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
