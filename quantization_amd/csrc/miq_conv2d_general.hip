@@ -182,14 +182,15 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
     }
 }
 
-// Depthwise layers (one input and one output channel a group) with stride 1 and dilation 1 along x and a filter 3, 5 or 7
-// wide: a lane owns four consecutive outputs of one output row and, per filter row, loads the KW + 3 activations under
-// them once (the kernel above loads KW per output and checks every one against the image: four times the instructions
-// of the arithmetic).  The units (image, channel, row, quad of pixels) are dealt over the lanes in that order, so small
-// images fill workgroups too; a lane reads its channel's filter straight from memory (KH * KW cached bytes).
-template <typename T, int OUT, int KW>
+// Depthwise layers (one input and one output channel a group) with stride 1 or 2 and dilation 1 along x and a filter 3, 5
+// or 7 wide: a lane owns four consecutive outputs of one output row and, per filter row, loads the 3 * SW + KW activations
+// under them once (the kernel above loads KW per output and checks every one against the image: four times the
+// instructions of the arithmetic).  The units (image, channel, row, quad of pixels) are dealt over the lanes in that order,
+// so small images fill workgroups too; a lane reads its channel's filter straight from memory (KH * KW cached bytes).
+template <typename T, int OUT, int KW, int SW>
 __global__ __launch_bounds__(256) void conv_depthwise_rows_kernel(GeneralArgs g, uint32_t units, int quads, int vec_in, int vec_out) {
     using Acc = std::conditional_t<std::is_same_v<T, int8_t>, int, float>;
+    constexpr int NX = 3 * SW + KW;   // activations of one filter row under four outputs
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
     if (u >= units) return;
     const uint32_t rowid = u / quads;                 // (image * C + channel) * Ho + ho
@@ -199,39 +200,44 @@ __global__ __launch_bounds__(256) void conv_depthwise_rows_kernel(GeneralArgs g,
     const int c = static_cast<int>(plane % g.Cout);
     const T* xp = static_cast<const T*>(g.x) + static_cast<size_t>(plane) * g.H * g.W;   // (Cin == Cout)
     const int8_t* wc = g.w + c * g.KH * KW;
-    const int iw0 = wo0 - g.pl;
-    bool col_ok[KW + 3];
+    const int iw0 = wo0 * SW - g.pl;
+    bool col_ok[NX];
 #pragma unroll
-    for (int k = 0; k < KW + 3; ++k) col_ok[k] = static_cast<unsigned>(iw0 + k) < static_cast<unsigned>(g.W);
+    for (int k = 0; k < NX; ++k) col_ok[k] = static_cast<unsigned>(iw0 + k) < static_cast<unsigned>(g.W);
+    // vec_in (wave-uniform: W % 4 == 0, aligned planes, pad_left <= KW - SW): the activations straight under the lane's
+    // outputs, columns wo0 * SW .. + 4 * SW - 1 = k in [pl, pl + 4 * SW), are SW aligned vectors of four; each is taken as one
+    // load where it lies inside the row (outputs may reach past it), and only the others are single loads
+    struct alignas(4 * sizeof(T)) Vec4 {
+        T e[4];
+    };
+    bool own[SW];
+#pragma unroll
+    for (int v = 0; v < SW; ++v) own[v] = vec_in && wo0 * SW + 4 * v + 4 <= g.W;
     Acc acc[4] = {0, 0, 0, 0};
     for (int kh = 0; kh < g.KH; ++kh) {
         const int ih = ho * g.sh - g.pt + kh * g.dh;
         if (static_cast<unsigned>(ih) >= static_cast<unsigned>(g.H)) continue;
         const T* xr = xp + ih * g.W + iw0;
-        Acc xv[KW + 3];
-        if (vec_in) {
-            // (wave-uniform) the four activations under the lane's own outputs, columns wo0 .. wo0 + 3 = k in [pl, pl + 3], are one
-            // aligned vector inside the image (W % 4 == 0, aligned planes); only the KW - 1 beside them are single loads
-            struct alignas(4 * sizeof(T)) Vec4 {
-                T e[4];
-            };
-            const Vec4 v = *reinterpret_cast<const Vec4*>(xr + g.pl);
+        Vec4 vv[SW];
 #pragma unroll
-            for (int k = 0; k < KW + 3; ++k) {
-                xv[k] = 0;
-                if (k >= g.pl && k < g.pl + 4) {
-                    const T e = k - g.pl == 0 ? v.e[0] : k - g.pl == 1 ? v.e[1] : k - g.pl == 2 ? v.e[2] : v.e[3];
+        for (int v = 0; v < SW; ++v)
+            if (own[v]) vv[v] = *reinterpret_cast<const Vec4*>(xr + g.pl + 4 * v);
+        Acc xv[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            xv[k] = 0;
+            const int r = k - g.pl;   // position among the lane's own columns
+            bool taken = false;
+#pragma unroll
+            for (int v = 0; v < SW; ++v) {
+                if (own[v] && r >= 4 * v && r < 4 * v + 4) {
+                    const int q = r - 4 * v;
+                    const T e = q == 0 ? vv[v].e[0] : q == 1 ? vv[v].e[1] : q == 2 ? vv[v].e[2] : vv[v].e[3];
                     xv[k] = load_x(&e);
-                } else if (col_ok[k]) {
-                    xv[k] = load_x(xr + k);
+                    taken = true;
                 }
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < KW + 3; ++k) {
-                xv[k] = 0;
-                if (col_ok[k]) xv[k] = load_x(xr + k);
-            }
+            if (!taken && col_ok[k]) xv[k] = load_x(xr + k);
         }
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
@@ -239,9 +245,9 @@ __global__ __launch_bounds__(256) void conv_depthwise_rows_kernel(GeneralArgs g,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (std::is_same_v<Acc, int>)
-                    acc[e] += xv[kw + e] * wv;
+                    acc[e] += xv[kw + e * SW] * wv;
                 else
-                    acc[e] = __builtin_fmaf(xv[kw + e], wv, acc[e]);
+                    acc[e] = __builtin_fmaf(xv[kw + e * SW], wv, acc[e]);
             }
         }
     }
@@ -282,22 +288,27 @@ __global__ __launch_bounds__(256) void conv_depthwise_rows_kernel(GeneralArgs g,
 template <typename T, int OUT>
 int launch_general(const GeneralArgs& a0, int64_t B, int64_t groups, hipStream_t st) {
     GeneralArgs a = a0;
-    if (a.cin_g == 1 && a.cout_g == 1 && a.sw == 1 && a.dw == 1 && (a.KW == 3 || a.KW == 5 || a.KW == 7)) {
+    if (a.cin_g == 1 && a.cout_g == 1 && (a.sw == 1 || a.sw == 2) && a.dw == 1 && (a.KW == 3 || a.KW == 5 || a.KW == 7)) {
         const int64_t quads = ceil_div(a.Wo, 4), units = B * a.Cout * a.Ho * quads;
-        if (units < (1ll << 31) && B * a.Cin * static_cast<int64_t>(a.H) * a.W < (1ll << 31) && static_cast<int64_t>(a.H) * a.W < (1ll << 31)) {
+        if (units < (1ll << 31) && static_cast<int64_t>(a.H) * a.W < (1ll << 31)) {
             const unsigned grid = static_cast<unsigned>(ceil_div(units, 256));
             const uint32_t nu = static_cast<uint32_t>(units);
             const int nq = static_cast<int>(quads);
-            // vectors of four: activations when every row of every plane starts on one and the lane's own four lie inside the
-            // filter's window (pad_left < KW); outputs when the output rows are whole vectors
-            const int vec_in = a.W % 4 == 0 && aligned(a.x, 4 * sizeof(T)) && a.pl <= a.KW - 1;
+            // vectors of four: activations when every row of every plane starts on one and the lane's own columns lie inside
+            // the filter's window (pad_left <= KW - stride); outputs when the output rows are whole vectors
+            const int vec_in = a.W % 4 == 0 && aligned(a.x, 4 * sizeof(T)) && a.pl <= a.KW - a.sw;
             const int vec_out = a.Wo % 4 == 0 && aligned(a.out, OUT == MIQ_BF16 ? 8 : 16);
-            if (a.KW == 3)
-                conv_depthwise_rows_kernel<T, OUT, 3><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
-            else if (a.KW == 5)
-                conv_depthwise_rows_kernel<T, OUT, 5><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
-            else
-                conv_depthwise_rows_kernel<T, OUT, 7><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out);
+#define MIQ_DW_ROWS(KW_, SW_) conv_depthwise_rows_kernel<T, OUT, KW_, SW_><<<grid, 256, 0, st>>>(a, nu, nq, vec_in, vec_out)
+            if (a.sw == 1) {
+                if (a.KW == 3) MIQ_DW_ROWS(3, 1);
+                else if (a.KW == 5) MIQ_DW_ROWS(5, 1);
+                else MIQ_DW_ROWS(7, 1);
+            } else {
+                if (a.KW == 3) MIQ_DW_ROWS(3, 2);
+                else if (a.KW == 5) MIQ_DW_ROWS(5, 2);
+                else MIQ_DW_ROWS(7, 2);
+            }
+#undef MIQ_DW_ROWS
             return check_launch("conv_depthwise_rows_kernel");
         }
     }

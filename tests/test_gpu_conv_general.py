@@ -58,6 +58,10 @@ CASES = [
     # a stride and a dilation along y, 'same')
     (2, 24, 13, 17, 24, (5, 5), 1, 2, 1, 24), (3, 10, 21, 18, 10, (7, 7), (2, 1), (3, 3), (2, 1), 10),
     (2, 6, 12, 10, 6, (2, 3), 1, "same", 1, 6), (1, 5, 8, 3, 5, (3, 3), 1, 1, 1, 5),
+    # ... rows of whole vectors whose outputs reach past the image (padding 2 under a 3 x 3 filter), and stride 2 along x
+    (2, 8, 10, 12, 8, (3, 3), 1, 2, 1, 8), (2, 8, 12, 16, 8, (5, 5), 1, (1, 4), 1, 8),
+    (3, 8, 16, 16, 8, (3, 3), 2, 1, 1, 8), (2, 12, 15, 20, 12, (5, 5), (1, 2), 2, 1, 12), (2, 6, 9, 12, 6, (7, 7), 2, (3, 5), 1, 6),
+    (4, 16, 30, 29, 16, (3, 3), 2, 1, 1, 16),
     # dense layers large enough for every tile shape of the implicit-GEMM kernels
     (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
     (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
