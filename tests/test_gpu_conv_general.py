@@ -262,3 +262,45 @@ def test_dense_layer_into_an_output_that_is_not_vector_aligned(N):
     N.conv2d_general(x.float(), w, (1, 2), (2, 1), (2, 1), 1, alpha=alpha, out=y)
     want = ref.double() * alpha.double().view(1, -1, 1, 1)
     np.testing.assert_allclose(y.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+def test_random_layers_vs_torch(N):
+    """Seeded random layers over the whole argument space (groups, dilation, stride and padding per axis, 'same' / 'valid',
+    ragged sizes): int8 activations exact against float64 F.conv2d, fp32 / fp16 / bf16 activations within the kernel's bar."""
+    import random
+    rnd = random.Random(77)
+    for i in range(80):
+        g = rnd.choice([1, 1, 1, 2, 3, 4, 8, 16])
+        cin_g, cout_g = rnd.choice([1, 1, 2, 3, 5, 8, 16, 24]), rnd.choice([1, 1, 2, 3, 6, 8, 17, 40])
+        if g == 1:
+            cin_g, cout_g = rnd.randint(1, 70), rnd.randint(1, 90)
+        C, Co = g * cin_g, g * cout_g
+        k = (rnd.choice([1, 2, 3, 3, 5, 7]), rnd.choice([1, 2, 3, 3, 5, 7]))
+        d = (rnd.choice([1, 1, 2, 3]), rnd.choice([1, 1, 1, 2]))
+        s = (rnd.choice([1, 1, 2, 3]), rnd.choice([1, 1, 2]))
+        mode = rnd.random()
+        if mode < 0.15:
+            p, s = "same", (1, 1)
+        elif mode < 0.25:
+            p = "valid"
+        else:
+            p = (rnd.randint(0, 3), rnd.randint(0, 3))
+        eh, ew = d[0] * (k[0] - 1) + 1, d[1] * (k[1] - 1) + 1
+        H, W = eh + rnd.randint(0, 30), ew + rnd.choice([rnd.randint(0, 30), 4 * rnd.randint(0, 8)])
+        B = rnd.randint(1, 5)
+        x, w = rand_i8((B, C, H, W), 5000 + i), rand_i8((Co, cin_g, *k), 6000 + i)
+        kw = torch_args(s, p, d, g)
+        ref = F.conv2d(x.cuda().double(), w.cuda().double(), **kw)
+        out = N.conv2d_general(x.cuda(), w.cuda(), s, p, d, g, out_dtype=torch.int32)
+        assert out.shape == ref.shape and torch.equal(out, ref.to(torch.int32)), (i, B, C, H, W, Co, k, s, p, d, g)
+        xdt = rnd.choice(["f32", "f16", "bf16"])
+        gen = torch.Generator().manual_seed(7000 + i)
+        xf = torch.randn(B, C, H, W, generator=gen).to(DT[xdt])
+        alpha = torch.rand(Co, generator=gen) * 0.02 + 1e-4
+        b = torch.randn(Co, generator=gen) * 5
+        y = N.conv2d_general(xf.cuda(), w.cuda(), s, p, d, g, bias=b.cuda(), alpha=alpha.cuda())
+        a4 = alpha.double().view(1, -1, 1, 1)
+        reff = (F.conv2d(xf.double(), w.double(), **kw) + b.double().view(1, -1, 1, 1)) * a4
+        mag = (F.conv2d(xf.double().abs(), w.double().abs(), **kw) + b.double().abs().view(1, -1, 1, 1)) * a4
+        worst = float(((y.cpu().double() - reff).abs() / (5e-5 * mag + 1e-30)).max())
+        assert worst <= 1.0, (i, xdt, worst, B, C, H, W, Co, k, s, p, d, g)
