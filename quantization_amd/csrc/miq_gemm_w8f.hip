@@ -1482,7 +1482,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
 // Geometry of the patch path, or ok = false when the layer does not take it: 3 x 3 / stride 1, whole 32-channel groups,
 // enough pixels for every CU, and a patch that fits the LDS planes.
 // Activation planes of the patch and im2col-order convolution kernels: fp32 as hi + lo bf16, bf16 and fp16 as they are.
-// (The stem kernel packs hi | lo of fp16 activations into one 16-byte pixel as it does for fp32.)
 inline int conv_w8_planes(int x_dtype) { return x_dtype == MIQ_F32 ? 2 : 1; }
 
 struct PatchW8Geom {
@@ -1628,7 +1627,7 @@ __global__ __launch_bounds__(256) void stem_w8_prep_kernel(const T* __restrict__
                 for (int c = 0; c < 4; ++c) {
                     if (c >= Cin) break;
                     const float v = to_f32(src[c * cs]);
-                    fh[c] = bf16_round(v);
+                    fh[c] = kPlaneF16<T, NP> ? v : bf16_round(v);   // fp16 activations as one plane keep their format
                     if constexpr (NP == 2) {
                         if (__builtin_isinf(fh[c]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
                             fh[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
@@ -1636,7 +1635,10 @@ __global__ __launch_bounds__(256) void stem_w8_prep_kernel(const T* __restrict__
                     }
                 }
             }
-            xp[idx] = uint4{pack2_bf16(fh[0], fh[1]), pack2_bf16(fh[2], fh[3]), pack2_bf16(fl[0], fl[1]), pack2_bf16(fl[2], fl[3])};
+            if constexpr (kPlaneF16<T, NP>)   // (fh holds the fp16 values themselves: see below)
+                xp[idx] = uint4{pack2_f16(fh[0], fh[1]), pack2_f16(fh[2], fh[3]), 0u, 0u};
+            else
+                xp[idx] = uint4{pack2_bf16(fh[0], fh[1]), pack2_bf16(fh[2], fh[3]), pack2_bf16(fl[0], fl[1]), pack2_bf16(fl[2], fl[3])};
         }
         return;
     }
@@ -1651,13 +1653,15 @@ __global__ __launch_bounds__(256) void stem_w8_prep_kernel(const T* __restrict__
             for (int c = 0; c < 4; ++c)
                 if (c < Cin) v[c] = static_cast<float>(w[((static_cast<size_t>(n) * Cin + c) * KH + kh) * KW + kw]);
         }
-        const uint32_t lo = pack2_bf16(v[0], v[1]), hi = pack2_bf16(v[2], v[3]);
+        const uint32_t lo = kPlaneF16<T, NP> ? pack2_f16(v[0], v[1]) : pack2_bf16(v[0], v[1]);
+        const uint32_t hi = kPlaneF16<T, NP> ? pack2_f16(v[2], v[3]) : pack2_bf16(v[2], v[3]);
         wp[idx] = NP == 2 ? uint4{lo, hi, lo, hi} : uint4{lo, hi, 0u, 0u};
     }
 }
 
-template <int OUT>
+template <int OUT, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_stem_w8_kernel(StemW8Args g) {
+    using frag_t = typename W8Frag<F16>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, the channel tile's filters
     char* const wst = smem + 2 * kStemW8PatchBytes;
     const int lane = threadIdx.x & 63;
@@ -1740,16 +1744,16 @@ __global__ __launch_bounds__(512, 2) void conv_stem_w8_kernel(StemW8Args g) {
             for (int f = 0; f < 4; ++f) acc[i][f] = v4f{0.f, 0.f, 0.f, 0.f};
         const char* a_lane = smem + buf * kStemW8PatchBytes + a_off;
         for (int j = 0; j < g.ksteps; ++j) {
-            v8bf af[4], wf[4];
+            frag_t af[4], wf[4];
             const char* a = a_lane + ((j >> 1) * kStemW8Pitch + (j & 1) * 4) * kChunk;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) wf[f] = __builtin_bit_cast(v8bf, lds_read16(w_lane + j * 4096 + f * 256));
+            for (int f = 0; f < 4; ++f) wf[f] = __builtin_bit_cast(frag_t, lds_read16(w_lane + j * 4096 + f * 256));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(v8bf, lds_read16(a + i * 32 * kChunk));
+            for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(frag_t, lds_read16(a + i * 32 * kChunk));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[f], acc[i][f], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) acc[i][f] = mfma_w8<F16>(af[i], wf[f], acc[i][f]);
         }
 
         // D[R][c] of fragment (i, f): R = 4*(lane>>4) + reg -> pixel i*16 + R of the wave's row, c = lane&15 -> channel f*16 + c
@@ -1821,7 +1825,7 @@ int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w
     if (x_dtype == MIQ_F32)
         MIQ_STEM_PREP(float, 2);
     else if (x_dtype == MIQ_F16)
-        MIQ_STEM_PREP(_Float16, 2);
+        MIQ_STEM_PREP(_Float16, 1);
     else
         MIQ_STEM_PREP(__bf16, 1);
 #undef MIQ_STEM_PREP
@@ -1837,6 +1841,7 @@ int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w
     constexpr int kLds = 2 * kStemW8PatchBytes + kStemW8WeightBytes;
     static_assert(kLds <= 160 * 1024, "LDS of one CU");
     void (*kern)(StemW8Args) = out_dtype == MIQ_F32 ? conv_stem_w8_kernel<kOutF32> : conv_stem_w8_kernel<kOutBF16>;
+    if (x_dtype == MIQ_F16) kern = out_dtype == MIQ_F32 ? conv_stem_w8_kernel<kOutF32, true> : conv_stem_w8_kernel<kOutBF16, true>;
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), kLds)) return rc;
     int grid = a.units < 256 ? a.units : 256 - 256 % a.tiles_n;   // one persistent workgroup per CU, each keeping one channel tile
     if (grid < a.tiles_n) grid = a.units < a.tiles_n ? a.units : a.tiles_n;
