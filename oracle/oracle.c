@@ -4,7 +4,7 @@
  * __graft_entry__.smoke(), bench.py's cpu_baseline leg).  Nothing in quantization_amd/
  * links, loads or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py checks these functions against
+ * Parity status: PINNED.  tests/test_oracle_golden.py (test_c_oracle_*) checks these functions against
  * fixtures produced by the reference's own Python (oracle/gen_golden.py), and against the
  * numpy restatement in oracle/oracle_np.py on random inputs.
  *

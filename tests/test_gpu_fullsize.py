@@ -99,7 +99,12 @@ def test_quantizer_every_element_against_true_division(N, dtype, mode):
 @pytest.mark.parametrize("M,Nn,K", [(4096, 4096, 4096), (8192, 8192, 8192), (256, 14336, 4096), (256, 4096, 14336),
                                      (2048, 28672, 8192), (16, 14336, 4096), (1, 4096, 14336),
                                      # 128-row ring tiles: 128 x 128 (one round of tiles) and 128 x 256 (deep K)
-                                     (1000, 4096, 4096), (384, 12288, 8192), (256, 28672, 8192)])
+                                     (1000, 4096, 4096), (384, 12288, 8192), (256, 28672, 8192),
+                                     # the K = 28672 down projection of the Llama-3-70B MLP, and the token counts in between
+                                     # on the Llama-3-8B gate / up projection
+                                     (256, 8192, 28672), (2048, 8192, 28672),
+                                     (2, 14336, 4096), (4, 14336, 4096), (8, 14336, 4096), (32, 14336, 4096),
+                                     (64, 14336, 4096), (128, 14336, 4096)])
 def test_gemm_full_size_checksums(N, M, Nn, K):
     a, w = rand_i8((M, K), M + K), rand_i8((Nn, K), Nn + 7 * K)
     c = N.gemm_i8(a, w, out_dtype=torch.int32)

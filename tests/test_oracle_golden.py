@@ -195,3 +195,77 @@ def test_pool_oracle_matches_reference_fixture():
 def test_cast_to_int8_wraps_like_the_host_cast():
     v = np.array([1.9, -1.9, 127.9, 128.0, 200.0, 300.5, -129.7, -300.2, 1e10, -1e10, np.nan, np.inf], dtype=np.float32)
     np.testing.assert_array_equal(O.cast_f32_to_int8(v), np.array([1, -1, 127, -128, -56, 44, 127, -44, 0, 0, 0, 0], np.int8))
+
+
+# ---- the C restatement (oracle/oracle.c), pinned directly: the GPU parity tests use it as their checker ----
+
+from oracle import oracle_c as OC
+
+
+@pytest.mark.parametrize("case", [c for c in QW.cases() if kind_of(c) == "f32"])
+def test_c_oracle_quantizer_matches_reference(case):
+    """miq_oracle_quantize_rows_sym_i8 against the reference's own outputs (fp32 cases; the C function takes fp32)."""
+    w = QW.get(case, "w")
+    q, s, zp = OC.quantize_rows_sym_i8(w)
+    np.testing.assert_array_equal(q, QW.get(case, "q"))
+    np.testing.assert_array_equal(s, QW.get(case, "scales").reshape(-1))
+    np.testing.assert_array_equal(zp, QW.get(case, "zp").reshape(-1))
+    assert q.dtype == np.int8 and s.dtype == np.float32 and zp.dtype == np.int64
+
+
+@pytest.mark.parametrize("case", FW.cases())
+def test_c_oracle_forward_matches_reference(case):
+    """linear_i8_nt / linear_w8a8 / conv2d_i8 + epilogue_f32 of oracle.c on the reference's weight-only forward
+    fixtures: bit-equal to the numpy restatement, and to the reference's float output at 1e-6."""
+    x, q, s, bias = FW.get(case, "x"), FW.get(case, "q"), FW.get(case, "scales"), FW.get(case, "bias")
+    xi = x.astype(np.int8)
+    np.testing.assert_array_equal(xi.astype(x.dtype), x)      # the fixtures' activations are integer-valued
+    if case.startswith("lin"):
+        acc = OC.linear_i8_nt(xi, q)
+        np.testing.assert_array_equal(acc, OC.linear_w8a8(xi, np.ascontiguousarray(q.T)))
+        np.testing.assert_array_equal(acc, O.linear_w8a8(xi, np.ascontiguousarray(q.T)))
+        y_np = O.wo_linear_forward(x, q, s, bias)
+    else:
+        stride, pad = (int(v) for v in FW.get(case, "stride_pad"))
+        acc = OC.conv2d_i8(xi, q, stride, pad)
+        np.testing.assert_array_equal(acc, O.conv2d_int8(xi, q, stride, pad))
+        y_np = O.wo_conv2d_forward(x, q, s, bias, stride, pad)
+    y = OC.epilogue_f32(acc, bias, s, 0.0)
+    np.testing.assert_array_equal(y, O.epilogue(acc, bias, s, 0.0))
+    np.testing.assert_array_equal(y, y_np)
+    ref = FW.get(case, "y")
+    np.testing.assert_allclose(y, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+
+
+def test_c_oracle_wa_epilogue_matches_reference():
+    """epilogue_f32 with the weight+activation parameters (bias', scalers, output zero point) of the reference's
+    calibrated SimpleCNN: bit-equal to the numpy epilogue, 2e-6 from the reference's float output."""
+    for name, conv in (("conv1", True), ("fc2", False)):
+        x, wq = WA.get(name, "x"), WA.get(name, "weight")
+        bias, scalers = WA.get(name, "bias"), WA.get(name, "scalers")
+        ozp = float(WA.get(name, "output_zero_point")[0])
+        acc = OC.conv2d_i8(x, wq, 1, 1) if conv else OC.linear_i8_nt(x, wq)
+        np.testing.assert_array_equal(acc, O.conv2d_int8(x, wq, 1, 1) if conv else O.linear_w8a8(x, np.ascontiguousarray(wq.T)))
+        y = OC.epilogue_f32(acc, bias, scalers, ozp)
+        np.testing.assert_array_equal(y, O.epilogue(acc, bias, scalers, ozp))
+        ref = WA.get(name, "y")
+        np.testing.assert_allclose(y, ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+
+
+def test_c_oracle_against_numpy_on_random_inputs():
+    rng = np.random.default_rng(7)
+    for shape in ((5, 33), (64, 27), (3, 4, 3, 3)):
+        w = (rng.standard_normal(shape) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
+        q, s, zp = OC.quantize_rows_sym_i8(w)
+        q2, s2, zp2 = O.quantize_channel_sym_int8(w)
+        np.testing.assert_array_equal(q, q2)
+        np.testing.assert_array_equal(s, s2.reshape(-1))
+        np.testing.assert_array_equal(zp, zp2.reshape(-1))
+    for (B, C, H, W, Co, k, st, p) in [(2, 3, 9, 7, 4, 3, 1, 0), (1, 5, 8, 8, 6, 3, 2, 1), (1, 3, 12, 12, 2, 7, 2, 3)]:
+        x = rng.integers(-128, 128, (B, C, H, W), dtype=np.int8)
+        w = rng.integers(-128, 128, (Co, C, k, k), dtype=np.int8)
+        np.testing.assert_array_equal(OC.conv2d_i8(x, w, st, p), O.conv2d_int8(x, w, st, p))
+    a = rng.integers(-128, 128, (37, 96), dtype=np.int8)
+    b = rng.integers(-128, 128, (96, 53), dtype=np.int8)
+    np.testing.assert_array_equal(OC.linear_w8a8(a, b), a.astype(np.int64) @ b.astype(np.int64))
+    np.testing.assert_array_equal(OC.linear_i8_nt(a, np.ascontiguousarray(b.T)), a.astype(np.int64) @ b.astype(np.int64))
