@@ -10,19 +10,23 @@ produced by the per-channel quantizer from seeded fp32 data.  With N > 1 each ra
 output channels of a [8192*N, 8192] layer (weak scaling); a step computes the rank's [8192, 8192]
 block straight into its slot of the gather buffer and all-gathers the blocks in place over RCCL, so
 every rank ends with all N blocks; the gather of one step overlaps the GEMM of the next (independent
-layers of a stack).  What travels is chosen by MIQ_BENCH_GATHER = bf16 (default: the epilogue rounds
-once to bf16, half the bytes), f32 (bit-identical to one GPU) or i8 (requantised with a static
-activation scale, a quarter); `extra.gather_variants` times all three.
+layers of a stack).  What travels is chosen by MIQ_BENCH_GATHER = f32 (default at every N: bit-identical
+to one GPU), bf16 (the epilogue rounds once to bf16, half the bytes) or i8 (requantised in the epilogue
+with a static activation scale, a quarter); `gather_variants` in bench_extra.json times all three.
 
-Rank 0 prints ONE JSON line.  `value` is whole-job int8 TOPS (2*M*N*K integer operations per
+Rank 0 prints ONE short JSON line, last.  `value` is whole-job int8 TOPS (2*M*N*K integer operations per
 layer).  `roofline` prices the GEMM kernel against the dense int8 MFMA peak with the kernel's own
-duration measured by HIP events on the launch stream.  `extra` holds the other configurations of
-BASELINE.json, each with its own roofline: the quantizer against HBM bandwidth, the Llama-3-8B MLP at
-one token (config 4), ResNet-18's convolutions at batch 256 (config 3), and `config5`: the
-Llama-3-70B shapes [28672,8192], [8192,28672], [8192,8192] split over the N ranks by output channel
-(strong scaling) at M = 256 / 2048 / 8192 with the GEMM / all-gather breakdown.  `cpu_baseline` is the
-reference's CPU path (restated in oracle/oracle_torch.py, pinned to the reference by fixtures) on a
-bounded sample of the workload.
+duration measured by HIP events on the launch stream, and carries the other half of the metric as
+`roofline.quantizer` (the quantizer against HBM bandwidth) plus one number per other configuration
+(`roofline.others`).  The full tables of the other configurations of BASELINE.json, each with its own
+roofline -- the quantizer shapes, the Llama-3-8B MLP at one token (config 4), ResNet-18's convolutions
+at batch 256 with a fraction per layer (config 3), and `config5`: the Llama-3-70B shapes [28672,8192],
+[8192,28672], [8192,8192] split over the N ranks by output channel (strong scaling) at M = 256 / 2048 /
+8192 with the GEMM / all-gather breakdown -- go to the file bench_extra.json (under gpurun_out/ when
+that directory exists), not to stdout.  `cpu_baseline` is the reference's CPU path (restated in
+oracle/oracle_torch.py, pinned to the reference by fixtures) on a bounded sample of the workload.
+
+The output type of the headline step is fp32 at every --gpus N (MIQ_BENCH_GATHER=bf16|i8 overrides it).
 """
 import argparse
 import hashlib
@@ -235,16 +239,18 @@ def conv_int8(N_, dev):
     the 14 x 14 one against the int8 MFMA peak); `stack` is the sum over all twenty, against the MFMA peak."""
     B = 256
     res = {"batch": B, "out_dtype": "int32", "timing": "per layer a HIP graph of 6 calls, replayed (call_ms, total_ms); call by call from Python beside it"}
-    total_ms, total_ops, eager_ms = 0.0, 0.0, 0.0
+    total_ms, total_ops, eager_ms, roof_ms = 0.0, 0.0, 0.0, 0.0
+    per_layer = {}
     for C, H, Co, k, s, p, times in RESNET18_CONVS:
         x = torch.randint(-128, 128, (B, C, H, H), dtype=torch.int32, device=dev).to(torch.int8)
         w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device=dev).to(torch.int8)
         Ho = (H + 2 * p - k) // s + 1
         outs = [torch.empty(B, Co, Ho, Ho, dtype=torch.int32, device=dev) for _ in range(3)]
         it = [0]
+        pk = N_.conv2d_i8_prepack(w, (B, C, H, H), s, p)   # once per layer, as Quantizer.from_float does
 
         def step():
-            N_.conv2d_i8(x, w, s, p, out_dtype=torch.int32, out=outs[it[0] % 3])
+            N_.conv2d_i8(x, w, s, p, out_dtype=torch.int32, out=outs[it[0] % 3], packed=pk)
             it[0] += 1
         eager = median_ms(step, 30, 30)
         ms = graphed_ms(step, 6, 10, 6)   # device time: the small layers' two launches are shorter than their enqueueing from Python
@@ -252,6 +258,11 @@ def conv_int8(N_, dev):
         total_ms += ms * times
         eager_ms += eager * times
         total_ops += ops * times
+        # a layer's own roofline: the longer of its MFMA time and its HBM time (int8 input + weight once + int32 output)
+        lay_roof = max(ops / (PEAK_INT8_TOPS * 1e12), (x.numel() + w.numel() + 4 * outs[0].numel()) / (PEAK_HBM_GBS * 1e9)) * 1e3
+        roof_ms += lay_roof * times
+        per_layer[f"{C}to{Co}_{H}x{H}_k{k}s{s}"] = {"call_ms": round(ms, 4), "roofline_ms": round(lay_roof, 4),
+                                                     "frac": round(lay_roof / ms, 3), "x": times}
         if (C, H, Co, k) in ((64, 56, 64, 3), (256, 14, 256, 3)):
             entry = {"call_ms": round(ms, 4), "call_ms_enqueued_from_python": round(eager, 4), "TOPS": round(ops / (ms * 1e-3) / 1e12, 1)}
             if H == 56:
@@ -260,8 +271,11 @@ def conv_int8(N_, dev):
                 entry["roofline"] = mfma_roofline(ops, ms)
             res[f"{C}to{Co}_{H}x{H}_k{k}s{s}"] = entry
         del x, w, outs
+    res["per_layer"] = per_layer
     res["stack"] = {"layers": 20, "total_ms": round(total_ms, 4), "total_ms_enqueued_from_python": round(eager_ms, 4), "TOPS": round(total_ops / (total_ms * 1e-3) / 1e12, 1),
-                    "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms)}
+                    "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms),
+                    "summed_layer_rooflines_ms": round(roof_ms, 4), "frac_of_summed_layer_rooflines": round(roof_ms / total_ms, 4),
+                    "filters": "packed once per layer (miq_conv2d_i8_prepack), as Quantizer.from_float does"}
     # The same twenty layers as an int8 pipeline hands them over: channels-last int8 in (border present), int8 out
     # requantised in the epilogue, written with the next layer's border (miq_conv2d_i8_nhwc): one kernel per layer, no
     # re-layout.  The first layer's three input channels are carried as four (a zero channel).
@@ -302,7 +316,7 @@ def conv_weight_only_float(N_, dev):
     B = 256
     res = {"batch": B, "out_dtype": "float32", "timing": "per layer a HIP graph of 6 calls, replayed"}
     for dt in (torch.float32, torch.bfloat16, torch.float16):
-        total_ms, total_ops = 0.0, 0.0
+        total_ms, total_ops, roof_ms, per_layer = 0.0, 0.0, 0.0, {}
         for C, H, Co, k, s, p, times in RESNET18_CONVS:
             x = torch.randn(B, C, H, H, device=dev).to(dt)
             w = torch.randint(-128, 128, (Co, C, k, k), dtype=torch.int32, device=dev).to(torch.int8)
@@ -310,17 +324,27 @@ def conv_weight_only_float(N_, dev):
             Ho = (H + 2 * p - k) // s + 1
             outs = [torch.empty(B, Co, Ho, Ho, device=dev) for _ in range(3)]
             it = [0]
+            pk = N_.conv2d_w8_prepack(w, x.dtype, (B, C, H, H), s, p)   # once per layer, as Quantizer.from_float does
 
             def step():
-                N_.conv2d_w8(x, w, s, p, alpha=alpha, out=outs[it[0] % 3])
+                N_.conv2d_w8(x, w, s, p, alpha=alpha, out=outs[it[0] % 3], packed=pk)
                 it[0] += 1
             ms = graphed_ms(step, 6, 8, 4)
+            ops = 2.0 * B * Co * Ho * Ho * C * k * k
             total_ms += ms * times
-            total_ops += 2.0 * B * Co * Ho * Ho * C * k * k * times
+            total_ops += ops * times
+            planes = 2 if dt == torch.float32 else 1   # MFMA passes per product
+            lay_roof = max(planes * ops / (PEAK_BF16_TFLOPS * 1e12),
+                           (x.numel() * x.element_size() + w.numel() + 4 * outs[0].numel()) / (PEAK_HBM_GBS * 1e9)) * 1e3
+            roof_ms += lay_roof * times
+            per_layer[f"{C}to{Co}_{H}x{H}_k{k}s{s}"] = {"call_ms": round(ms, 4), "roofline_ms": round(lay_roof, 4),
+                                                         "frac": round(lay_roof / ms, 3), "x": times}
             del x, w, outs
         res[f"stack_{str(dt).split('.')[-1]}"] = {
             "layers": 20, "total_ms": round(total_ms, 4), "TFLOPs": round(total_ops / (total_ms * 1e-3) / 1e12, 1),
-            "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms, PEAK_BF16_TFLOPS)}
+            "images_per_s": round(B / (total_ms * 1e-3)), "roofline": mfma_roofline(total_ops, total_ms, PEAK_BF16_TFLOPS),
+            "summed_layer_rooflines_ms": round(roof_ms, 4), "frac_of_summed_layer_rooflines": round(roof_ms / total_ms, 4),
+            "per_layer": per_layer}
     return res
 
 
@@ -367,7 +391,7 @@ def config5(N_, dev, world, rank, dist, m_list=(256, 2048, 8192)):
         scale = torch.rand(n_local, device=dev) * 0.01 + 1e-4
         layer = ColumnShardedLinear(wq, scale, None, n, out_dtype=torch.bfloat16)
         for M in m_list:
-            if rank == 0:
+            if rank == 0 and world > 1:
                 print(f"[bench] config 5: [{n},{k}] over {world} rank(s), M={M}", file=sys.stderr, flush=True)
             x = torch.randint(-128, 128, (M, k), dtype=torch.int32, device=dev).to(torch.int8)
             gemm_ms = median_ms(lambda: layer.compute_block(x), 9, 5)
@@ -408,16 +432,75 @@ def config5(N_, dev, world, rank, dist, m_list=(256, 2048, 8192)):
                         "bf16 output gathered in place", "gather_dtype": "bfloat16", "ranks": world, "cases": rows}
 
 
+def activation_quantizer(N_, dev):
+    """The dynamic per-tensor activation quantizer in front of the int8 GEMM (quant/Weight_Only/Quantizer.py:38-44
+    followed through): quantize_tensor_i8 on a [256,4096] fp32 activation and the whole linear_dynamic_w8a8 at M = 16
+    on the Llama-3-8B gate / up weight, whole calls as replayed HIP graphs."""
+    from quantization_amd import activation as A
+    res = {}
+    x = torch.randn(256, 4096, device=dev)
+    ms = graphed_ms(lambda: A.quantize_tensor_i8(x), 10, 10, 5)
+    res["quantize_tensor_[256,4096]_f32"] = {"call_ms": round(ms, 4), "roofline": hbm_roofline(x.numel() * 5, ms)}
+    Nn, K = 14336, 4096
+    ws = [torch.randint(-128, 128, (Nn, K), dtype=torch.int32, device=dev).to(torch.int8) for _ in range(6)]
+    rs = [A.weight_rowsum(w) for w in ws]
+    w_scale = torch.rand(Nn, device=dev) * 0.01 + 1e-4
+    for M in (16, 256):
+        xm = torch.randn(M, K, device=dev)
+        it = [0]
+
+        def call():
+            it[0] += 1
+            A.linear_dynamic_w8a8(xm, ws[it[0] % 6], w_scale, None, rs[it[0] % 6])
+        ms = graphed_ms(call, 12, 10, 5)
+        res[f"linear_dynamic_w8a8_M{M}_[14336,4096]"] = {"call_ms": round(ms, 4),
+                                                         "roofline": hbm_roofline(Nn * K + M * K * 5 + M * Nn * 4, ms)}
+    return res
+
+
+def quantizer_shapes(N_, dev):
+    """The per-channel quantizer on BASELINE config 4's weights and the 4096^2 one of config 2, beside the Llama-3-70B
+    shape of the headline record: rotating buffers well past the 256 MiB Infinity Cache, HIP events per launch
+    after a clock ramp, mean.  Algorithmic bytes: sizeof(w) + 1 per element + 12 per row."""
+    res = {}
+    for rows, cols, dt in ((14336, 4096, torch.float32), (14336, 4096, torch.bfloat16), (4096, 14336, torch.float32),
+                           (4096, 4096, torch.float32)):
+        esz = 4 if dt == torch.float32 else 2
+        nbuf = max(4, int(1.0e9 // (rows * cols * esz)) + 1)
+        ws = [(torch.randn(rows, cols, device=dev) * 0.02).to(dt) for _ in range(nbuf)]
+        it = [0]
+
+        def step():
+            N_.quantize_rows_sym_i8(ws[it[0] % nbuf])
+            it[0] += 1
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.15:
+            for _ in range(nbuf):
+                step()
+            torch.cuda.synchronize()
+        ts = event_times(step, 5 * nbuf)
+        ms = sum(ts) / len(ts)
+        nbytes = rows * cols * (esz + 1) + rows * 12
+        res[f"[{rows},{cols}]_{str(dt).split('.')[-1]}"] = {"kernel_ms": round(ms, 4), "roofline": hbm_roofline(nbytes, ms)}
+        del ws
+    return res
+
+
 def cpu_baseline(K, N, sample_rows, seed):
-    """Reference CPU path on a bounded sample: quantize a [1024, K] slab of the weight with the
-    reference's row loop, then weight-only forward of `sample_rows` rows against the full weight."""
+    """Reference CPU path on a bounded sample: weight-only forward of `sample_rows` rows against the full weight
+    (median of 5), and Qop.quantize with the reference's per-row Python loop on the whole Llama-3-8B gate / up
+    weight [14336,4096] (median of 3)."""
     from oracle import oracle_torch as T
     threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(seed)
-    w = torch.randn(N, K, generator=g) * 0.02
-    t0 = time.perf_counter()
-    T.quantize_channel_sym_int8(w[:1024])
-    tq = time.perf_counter() - t0
+    wq_full = torch.randn(14336, 4096, generator=g) * 0.02
+    tq = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T.quantize_channel_sym_int8(wq_full)
+        tq.append(time.perf_counter() - t0)
+    tq = sorted(tq)[1]
+    del wq_full
     wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int32).to(torch.int8)
     scale = torch.rand(N, generator=g) * 0.01 + 1e-4
     zp = torch.zeros(N, dtype=torch.int64)
@@ -425,20 +508,21 @@ def cpu_baseline(K, N, sample_rows, seed):
     x = torch.randint(-128, 128, (sample_rows, K), generator=g, dtype=torch.int32).float()
     T.wo_linear_forward(x[:64], wq, scale, zp, bias)   # warm the thread pool
     times = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         T.wo_linear_forward(x, wq, scale, zp, bias)
         times.append(time.perf_counter() - t0)
-    best = min(times)
+    med = sorted(times)[2]
     return {
-        "value": round(2.0 * sample_rows * N * K / best / 1e12, 4),
+        "value": round(2.0 * sample_rows * N * K / med / 1e12, 4),
         "unit": "TOPS",
         "cores": threads,
         "kind": "port",
-        "sample": f"weight-only forward of {sample_rows} of the {N} activation rows against the full "
-                  f"[{N},{K}] int8 weight (float GEMM + per-call weight cast, as the reference), best of 3",
-        "quantizer_GBps": round(1024 * K * 5 / tq / 1e9, 3),
-        "quantizer_sample": f"Qop.quantize of a [1024,{K}] fp32 slab (reference's per-row Python loop)",
+        "sample": f"WO forward, {sample_rows} of {N} rows x full [{N},{K}] int8 weight (float GEMM + weight cast), median of 5; "
+                  f"moves +-30% run to run",
+        "spread": [round(2.0 * sample_rows * N * K / t / 1e12, 3) for t in (max(times), min(times))],
+        "quantizer_GBps": round((14336 * 4096 * 5 + 14336 * 12) / tq / 1e9, 3),
+        "quantizer_sample": "Qop.quantize of the full fp32 [14336,4096] (per-row Python loop), median of 3",
     }
 
 
@@ -515,7 +599,7 @@ def main():
     del ws
     wq, scale, _ = N_.quantize_rows_sym_i8(w_local)
 
-    gather_name = os.environ.get("MIQ_BENCH_GATHER", "bf16" if world > 1 else "f32")
+    gather_name = os.environ.get("MIQ_BENCH_GATHER", "f32")   # the same output type at every --gpus N
     if gather_name not in GATHER_DTYPES:
         sys.exit(f"MIQ_BENCH_GATHER must be one of {sorted(GATHER_DTYPES)}")
 
@@ -549,13 +633,21 @@ def main():
             if p is not None:
                 p.wait()
 
+    region = [None, None]   # HIP events on the launch stream around the whole timed region of the headline run
+
     def timed(layer, steps, warmup, events=None):
         run_steps(layer, warmup)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if events is not None:
+            region[0] = torch.cuda.Event(enable_timing=True)
+            region[0].record()
         run_steps(layer, steps, events)
+        if events is not None:
+            region[1] = torch.cuda.Event(enable_timing=True)
+            region[1].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -579,9 +671,25 @@ def main():
     gemm_events = []
     elapsed = timed(layer, args.steps, args.warmup, gemm_events)
 
-    # --- GEMM kernel duration: the event pairs recorded around every launch of the timed region ----
+    # --- GEMM kernel duration --------------------------------------------------------------------
+    # Two measurements with HIP events on the launch stream: (a) pairs around every EVENT_EVERY-th launch of the timed
+    # region, less the interval an EMPTY pair measures (each record is a queue packet of its own, and the pair's
+    # interval contains it); (b) one pair around the whole timed region / steps (on one GPU the launches are back to
+    # back, so this is a launch's duration plus the gap to the next).  The kernel's duration is the smaller one; it
+    # cannot exceed the step that contains it.
     kt = [a.elapsed_time(b) for a, b in gemm_events]
-    k_ms = sum(kt) / len(kt)
+    empty = []
+    for _ in range(20):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        empty.append((a, b))
+    torch.cuda.synchronize()
+    empty_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    pair_ms = sum(kt) / len(kt) - empty_ms
+    region_ms = region[0].elapsed_time(region[1]) / args.steps
+    k_ms = min(pair_ms, region_ms) if world == 1 else pair_ms
+    k_ms = min(k_ms, elapsed / args.steps * 1e3)
     ops_layer = 2.0 * M * S * K
 
     extras = {}
@@ -589,8 +697,6 @@ def main():
         if world > 1:
             variants = {}
             for name in ("f32", "bf16", "i8"):
-                if rank == 0:
-                    print(f"[bench] headline step with the {name} gather", file=sys.stderr, flush=True)
                 lay = layer if name == gather_name else make_layer(name)
                 el = elapsed if name == gather_name else timed(lay, max(args.steps // 4, 5), 3)
                 st = args.steps if name == gather_name else max(args.steps // 4, 5)
@@ -608,7 +714,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = ops_layer * world / (ms_per_step * 1e-3) / 1e12
         achieved = ops_layer / (k_ms * 1e-3) / 1e12
-        out_name = {"f32": "float32", "bf16": "bfloat16", "i8": "float32 -> int8 (static activation scale)"}[gather_name]
+        out_name = {"f32": "float32", "bf16": "bfloat16", "i8": "int8 (requantised in the epilogue)"}[gather_name]
+        q_roof = hbm_roofline(q_bytes, q_ms)
         line = {
             "metric": "int8 linear TOPS (M=N=K=8192, fused per-channel dequant epilogue)",
             "value": round(value, 1),
@@ -616,7 +723,6 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_s": PREWARM_S,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -624,15 +730,12 @@ def main():
             "dtype": "int8",
             "data": "synthetic",
             "config": {
-                "workload": f"int8 linear M={M} N={S} per GPU ({n_total} total) K={K}, int8 activations x "
-                            "per-channel-quantized int8 weights -> int32 MFMA accumulate -> fused "
-                            f"(acc+bias)*scale epilogue, {out_name} out"
-                            + ("" if world == 1 else f"; column-sharded over {world} GPUs + in-place RCCL all-gather of the "
-                                                     f"{gather_name} blocks, overlapped with the next step's GEMM"),
+                "workload": f"int8 linear M={M} N={S}/GPU K={K}: int8 x per-channel int8 -> int32 MFMA -> (acc+bias)*scale, {out_name} out"
+                            + ("" if world == 1 else f"; x{world} column shards + in-place all-gather"),
                 "M": M, "N_per_gpu": S, "K": K, "out_dtype": out_name,
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world} + all-gather ({gather_name})",
                 "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
-                "untimed_before_warmup": f"{PREWARM_S} s of the same GEMM (clock ramp) on top of --warmup",
+                "prewarm_s": PREWARM_S,
             },
             "roofline": {
                 "bound": "mfma",
@@ -643,34 +746,49 @@ def main():
                 "traffic": profiled_traffic("gemm_i8_256_kernel") if S == 8192 else None,
                 "kernel": "gemm_i8_256_kernel",
                 "kernel_ms": round(k_ms, 4),
-                "note": "integer multiply-adds counted as 2 ops each (TOP/s); algorithmic work 2*M*N*K per launch; "
-                        "traffic = bytes per launch through the L2 <-> fabric ports from the rocprofv3 FETCH_SIZE/WRITE_SIZE "
-                        "passes recorded in profiles/r2_traffic.json for exactly these kernel sources (null otherwise); an upper "
-                        "bound of HBM bytes: it counts the fills of the eight per-XCD L2s, most of which the 256 MiB Infinity "
-                        "Cache serves (the operands themselves are 128 MiB, the output 256 MiB).  The chip lowers its clock under "
-                        "MFMAs on random int8 operands (~1.8 GHz under this kernel, 1.93 GHz under bare 16x16x64 MFMAs = 4.06 POPS, "
-                        "2.4 GHz on zeros: profiles/r2_gemm_power.txt, r2_gemm_wide.txt)",
-            },
-            "extra": {
-                "quantizer": {
-                    "workload": f"per-channel symmetric int8 quantize of fp32 [{QR},{QC}] (5 B/element + 12 B/row)",
-                    "GBps": round(q_bytes / (q_ms * 1e-3) / 1e9, 1),
-                    "kernel_ms": round(q_ms, 4),
-                    "roofline": dict(hbm_roofline(q_bytes, q_ms),
-                                     traffic=profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None),
-                },
+                "kernel_ms_event_pairs": round(pair_ms, 4),
+                "kernel_ms_region": round(region_ms, 4),
+                "quantizer": {"shape": f"fp32 [{QR},{QC}]", "GBps": q_roof["achieved"], "frac": q_roof["frac"],
+                              "kernel_ms": round(q_ms, 4), "bytes": q_bytes,
+                              "traffic": profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None},
             },
         }
-        line["extra"].update(extras)
+        extra = {"prewarm_s": PREWARM_S,
+                 "quantizer": {"workload": f"per-channel symmetric int8 quantize of fp32 [{QR},{QC}] (5 B/element + 12 B/row)",
+                               "kernel_ms": round(q_ms, 4), "roofline": q_roof}}
+        extra.update(extras)
         if world == 1 and not args.no_extras:
-            line["extra"]["gemm_other_shapes"] = gemm_other_shapes(N_, dev)
-            line["extra"]["llama3_8b_mlp_decode"] = llama8b_mlp_decode(N_, dev)
-            line["extra"]["weight_only_float"] = weight_only_float(N_, dev)
-            line["extra"]["conv_int8"] = conv_int8(N_, dev)
-            line["extra"]["conv_weight_only_float"] = conv_weight_only_float(N_, dev)
-            line["extra"]["conv_general"] = conv_general(N_, dev)
+            extra["quantizer_shapes"] = quantizer_shapes(N_, dev)
+            extra["gemm_other_shapes"] = gemm_other_shapes(N_, dev)
+            extra["llama3_8b_mlp_decode"] = llama8b_mlp_decode(N_, dev)
+            extra["weight_only_float"] = weight_only_float(N_, dev)
+            extra["conv_int8"] = conv_int8(N_, dev)
+            extra["conv_weight_only_float"] = conv_weight_only_float(N_, dev)
+            extra["conv_general"] = conv_general(N_, dev)
+            extra["activation_quantizer"] = activation_quantizer(N_, dev)
+            # one number per other configuration, inside the record the driver keeps
+            qs, go, dec = extra["quantizer_shapes"], extra["gemm_other_shapes"], extra["llama3_8b_mlp_decode"]
+            line["roofline"]["others"] = {
+                "quantizer_frac": {k: v["roofline"]["frac"] for k, v in qs.items()},
+                "gemm_frac": {k: v["roofline"]["frac"] for k, v in go.items()},
+                "decode_mlp_frac": {m: dec[m]["roofline"]["frac"] for m in ("M1", "M16")},
+                "decode_mlp_fused_frac": {m: dec[m]["fused_gate_up"]["roofline"]["frac"] for m in ("M1", "M16")},
+                "conv_int8_stack_ms": extra["conv_int8"]["stack"]["total_ms"],
+                "conv_int8_stack_roofline_frac": extra["conv_int8"]["stack"]["frac_of_summed_layer_rooflines"],
+                "conv_int8_nhwc_stack_ms": extra["conv_int8"]["stack_channels_last_int8"]["total_ms"],
+                "conv_w8_stack_ms": {k.replace("stack_", ""): v["total_ms"] for k, v in extra["conv_weight_only_float"].items()
+                                     if k.startswith("stack_")},
+                "dynamic_w8a8_M16_ms": extra["activation_quantizer"]["linear_dynamic_w8a8_M16_[14336,4096]"]["call_ms"],
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)
+        # the long tables go to a file; stdout carries the one short record, last
+        out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+        try:
+            with open(os.path.join(out_dir, "bench_extra.json"), "w") as f:
+                json.dump({"headline": line, "extra": extra}, f, indent=1)
+        except OSError as e:
+            print(f"[bench] bench_extra.json not written: {e}", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

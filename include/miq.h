@@ -175,6 +175,25 @@ int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_
                   const float* alpha, float beta, void* out, int out_dtype, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* miq_conv2d_w8 with the filter re-laid ONCE, when the layer is built, instead of by every call (the reference's layers
+ * fix their int8 weight in Quantizer.from_float, quant/Weight_Only/Quantizer.py:93-112, the one place it changes; its
+ * forward re-casts the whole weight on every call, Quantizer.py:73).
+ *   miq_conv2d_w8_pack_weight: OIHW int8 w -> wp (miq_conv2d_w8_packed_weight_bytes bytes, 256-byte aligned), the forms
+ *     the kernels stage from for activations of x_dtype (im2col-order rows; for 3 x 3 filters over whole 32-channel groups
+ *     and for stems the filters widened to bf16 / fp16 in the layout of the LDS stage).  wp depends on the filter's shape
+ *     and on x_dtype only, not on the images the layer is later given.
+ *   miq_conv2d_w8_prepacked: miq_conv2d_w8 with `wp` in place of `w`; same results bit for bit.  workspace: at least
+ *     miq_conv2d_w8_prepacked_workspace(...) bytes (the activation planes only). */
+size_t miq_conv2d_w8_packed_weight_bytes(int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW);
+int miq_conv2d_w8_pack_weight(const int8_t* w, int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, void* wp,
+                              void* stream);
+size_t miq_conv2d_w8_prepacked_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                         int64_t KH, int64_t KW, int64_t stride, int64_t pad);
+int miq_conv2d_w8_prepacked(const void* x, int x_dtype, const void* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                            int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                            const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* dst[c,r] = src[r,c] for an int8 matrix src[rows, cols] (both dense).  Used to turn the
  * [K,N] weight of linear_w8a8 into the [N,K] layout once, ahead of repeated GEMMs. */
 int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, int8_t* dst, void* stream);
@@ -200,13 +219,25 @@ int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int6
                   const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* miq_conv2d_i8 with the filter re-laid once, when the layer is built (Quantizer.from_float,
+ * quant/Weight_Only/Quantizer.py:93-112, is the one place the reference's weight changes): `wp` is the packed weight of
+ * miq_conv2d_i8_pack_weight below (it depends on the filter's shape only), the workspace holds the padded copy of x only
+ * (miq_conv2d_i8_prepacked_workspace bytes).  Same results as miq_conv2d_i8 bit for bit. */
+size_t miq_conv2d_i8_prepacked_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                                         int64_t KW, int64_t stride, int64_t pad);
+int miq_conv2d_i8_prepacked(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                            int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad,
+                            const float* bias, const float* alpha, float beta, void* out, int out_dtype,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* int8 Conv2d on channels-last activations: the form in which a stack of int8 layers hands its activations from
  * one layer to the next without any re-layout pass (miq_conv2d_i8 above spends about a quarter of a ResNet-18 stack
  * turning NCHW into this form, layer by layer).  Same arithmetic and epilogue as miq_conv2d_i8, which replaces
  * conv2d_int8 (cuda_kernels/conv2d_int8/conv2d_w8a8.cu:81-114) and the Conv2d forward of the Python layers; the
  * channels-last layout and the int8 output have no counterpart in the reference, whose kernel is NCHW only.
  *   x:   int8 [B][H + 2*pad][W + 2*pad][Cin], the border already present and zero, Cin % 4 == 0, 16-byte aligned.
- *   wp:  the OIHW weight re-laid once by miq_conv2d_i8_pack_weight (miq_conv2d_i8_packed_weight_bytes bytes).
+ *   wp:  the OIHW weight re-laid once by miq_conv2d_i8_pack_weight (miq_conv2d_i8_packed_weight_bytes bytes, 16-byte
+ *        aligned; the same packed weight serves miq_conv2d_i8_prepacked).
  *   out: [B][Ho + 2*out_pad][Wo + 2*out_pad][Cout], Cout % 4 == 0; only the Ho x Wo interior is written, so a buffer
  *        whose border was zeroed once serves as the next layer's x as it is.  out_dtype MIQ_I32 (raw sums), MIQ_F32 /
  *        MIQ_BF16 ((acc + bias[c]) * alpha[c] + beta), or MIQ_I8: that value requantised, clamp(rint(.), -128, 127),

@@ -47,6 +47,12 @@ SYMBOLS = {
     "miq_transpose_i8": (_int, [_p, _i64, _i64, _p, _p]),
     "miq_conv2d_i8_workspace": (_size, [_i64] * 9),
     "miq_conv2d_i8": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_conv2d_i8_prepacked_workspace": (_size, [_i64] * 9),
+    "miq_conv2d_i8_prepacked": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_conv2d_w8_packed_weight_bytes": (_size, [_int] + [_i64] * 4),
+    "miq_conv2d_w8_pack_weight": (_int, [_p, _int] + [_i64] * 4 + [_p, _p]),
+    "miq_conv2d_w8_prepacked_workspace": (_size, [_int] + [_i64] * 9),
+    "miq_conv2d_w8_prepacked": (_int, [_p, _int, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
     "miq_conv2d_i8_packed_weight_bytes": (_size, [_i64] * 4),
     "miq_conv2d_i8_pack_weight": (_int, [_p] + [_i64] * 4 + [_p, _p]),
     "miq_conv2d_i8_nhwc": (_int, [_p, _p] + [_i64] * 9 + [_p, _p, ctypes.c_float, _p, _int, _i64, _p]),
@@ -357,8 +363,29 @@ def gemm_w8(x, w, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=
     return out
 
 
-def conv2d_w8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
-    """Weight-only Conv2d: floating-point NCHW x (fp32 / fp16 / bf16), int8 OIHW w, per-channel (acc + bias) * alpha + beta."""
+def conv2d_w8_pack_weight(w, x_dtype):
+    """OIHW int8 weight -> the packed form miq_conv2d_w8_prepacked stages from for activations of `x_dtype` (once per layer)."""
+    require_device(w, "kernel")
+    if w.dtype != torch.int8 or w.dim() != 4 or x_dtype not in _FLOAT_CODES:
+        raise RuntimeError("kernel must be a 4-D int8 tensor (OIHW) and x_dtype fp32 / fp16 / bf16")
+    Co, Ci, KH, KW = w.shape
+    L = lib()
+    code = _FLOAT_CODES[x_dtype]
+    wp = torch.empty(max(L.miq_conv2d_w8_packed_weight_bytes(code, Ci, Co, KH, KW), 256), dtype=torch.int8, device=w.device)
+    with _on(w.device):
+        _check(L.miq_conv2d_w8_pack_weight(_ptr(w), code, Ci, Co, KH, KW, _ptr(wp), _stream()))
+    return wp
+
+
+def conv2d_w8_prepack(w, x_dtype, x_shape=None, stride=1, padding=0):
+    """The `packed=` argument of conv2d_w8 for this filter and activation type (x_shape, stride and padding are not
+    needed: the packed weight depends on the filter's shape and the activation type only)."""
+    return conv2d_w8_pack_weight(w, x_dtype)
+
+
+def conv2d_w8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None, packed=None):
+    """Weight-only Conv2d: floating-point NCHW x (fp32 / fp16 / bf16), int8 OIHW w, per-channel (acc + bias) * alpha + beta.
+    packed: conv2d_w8_pack_weight(w, x.dtype), made once per layer; the call then skips the filter re-layout."""
     require_device(x, "input")
     require_device(w, "kernel")
     if x.dtype not in _FLOAT_CODES or w.dtype != torch.int8:
@@ -385,6 +412,16 @@ def conv2d_w8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
             raise RuntimeError("out has the wrong shape or dtype")
     L = lib()
     code = _FLOAT_CODES[x.dtype]
+    if packed is not None:
+        require_device(packed, "packed kernel")
+        if packed.dtype != torch.int8 or packed.numel() < L.miq_conv2d_w8_packed_weight_bytes(code, C, Co, KH, KW):
+            raise RuntimeError("packed kernel does not belong to this filter shape / activation type")
+        need = L.miq_conv2d_w8_prepacked_workspace(code, B, C, H, W, Co, KH, KW, stride, padding)
+        ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)
+        with _on(x.device):
+            _check(L.miq_conv2d_w8_prepacked(_ptr(x), code, _ptr(packed), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias),
+                                             _ptr(alpha), float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+        return out
     need = L.miq_conv2d_w8_workspace(code, B, C, H, W, Co, KH, KW, stride, padding)
     ws = torch.empty(need, dtype=torch.int8, device=x.device) if need else None
     with _on(x.device):
@@ -393,8 +430,14 @@ def conv2d_w8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
     return out
 
 
-def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
-    """NCHW int8 x, OIHW int8 w -> NCHW out with the per-channel epilogue of gemm_i8."""
+def conv2d_i8_prepack(w, x_shape=None, stride=1, padding=0):
+    """The `packed=` argument of conv2d_i8 for this filter (the packed weight depends on the filter's shape only)."""
+    return conv2d_i8_pack_weight(w)
+
+
+def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None, packed=None):
+    """NCHW int8 x, OIHW int8 w -> NCHW out with the per-channel epilogue of gemm_i8.
+    packed: conv2d_i8_pack_weight(w), made once per layer; the call then skips the filter re-layout."""
     require_device(x, "input")
     require_device(w, "kernel")
     if x.dtype != torch.int8 or w.dtype != torch.int8:
@@ -423,6 +466,16 @@ def conv2d_i8(x, w, stride=1, padding=0, bias=None, alpha=None, beta=0.0, out_dt
         if tuple(out.shape) != (B, Co, Ho, Wo) or out.dtype != out_dtype or out.device != x.device:
             raise RuntimeError("out has the wrong shape, dtype or device")
     L = lib()
+    if packed is not None:
+        require_device(packed, "packed kernel")
+        if packed.dtype != torch.int8 or packed.numel() < L.miq_conv2d_i8_packed_weight_bytes(C, Co, KH, KW):
+            raise RuntimeError("packed kernel does not belong to this filter shape")
+        need = L.miq_conv2d_i8_prepacked_workspace(B, C, H, W, Co, KH, KW, stride, padding)
+        ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)
+        with _on(x.device):
+            _check(L.miq_conv2d_i8_prepacked(_ptr(x), _ptr(packed), B, C, H, W, Co, KH, KW, stride, padding, _ptr(bias),
+                                             _ptr(alpha), float(beta), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+        return out
     need = L.miq_conv2d_i8_workspace(B, C, H, W, Co, KH, KW, stride, padding)
     ws = torch.empty(max(need, 1), dtype=torch.int8, device=x.device)
     with _on(x.device):

@@ -1827,6 +1827,30 @@ extern "C" int miq_transpose_i8(const int8_t* src, int64_t rows, int64_t cols, i
     return miq::check_launch("transpose_bytes_kernel");
 }
 
+// The packed weight (miq_conv2d_i8_pack_weight), shared by the channels-last entry point and miq_conv2d_i8_prepacked: the
+// im2col-order form wp[Cout][KH][Lp] and, for 3 x 3 filters over whole 64-channel groups, behind it (at the next multiple
+// of 256 bytes) the form conv3x3_patch_kernel stages from (output channels rounded up to whole tiles of 64, zero filled).
+// It depends on the filter's shape only, so a layer packs once, whatever images it is later given.
+struct PackedWeight {
+    int64_t rows_bytes;     // the im2col-order form
+    int64_t planar_at;      // offset of the patch kernel's form; 0 = none
+    int64_t planar_bytes;
+    int64_t total;
+};
+
+static PackedWeight packed_weight_layout(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
+    PackedWeight pw{};
+    const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
+    pw.rows_bytes = Cout * KH * Lp;
+    pw.total = pw.rows_bytes;
+    if (KH == 3 && KW == 3 && Cin % 64 == 0) {
+        pw.planar_at = miq::round_up(pw.rows_bytes, 256);
+        pw.planar_bytes = miq::ceil_div(Cout, 64) * (Cin / 64) * kWStageBytes;
+        pw.total = pw.planar_at + pw.planar_bytes;
+    }
+    return pw;
+}
+
 extern "C" size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvGeom g;
@@ -1834,10 +1858,12 @@ extern "C" size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int
     return static_cast<size_t>(miq::round_up(g.xp_bytes, 256) + miq::round_up(g.wp_bytes, 256));
 }
 
-extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
-                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
-                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+// `w` is the OIHW filter (prepacked = false: it is re-laid into the workspace by this call, behind the padded copy) or the
+// packed weight of miq_conv2d_i8_pack_weight (prepacked = true: the workspace holds the padded copy only).
+static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                         int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                         const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                         size_t workspace_bytes, void* stream) {
     ConvGeom G;
     MIQ_REQUIRE(make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G), MIQ_EINVAL,
                 "miq_conv2d_i8: bad geometry (B=%lld Cin=%lld H=%lld W=%lld Cout=%lld KH=%lld KW=%lld stride=%lld pad=%lld)",
@@ -1855,7 +1881,8 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
     const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
     MIQ_REQUIRE(miq::aligned(out, 4 * esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
                 "miq_conv2d_i8: out must be 16-byte (8 for bf16) aligned, alpha/bias 4-byte aligned");
-    const size_t need = miq_conv2d_i8_workspace(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    const size_t need = prepacked ? static_cast<size_t>(miq::round_up(G.xp_bytes, 256))
+                                  : miq_conv2d_i8_workspace(B, Cin, H, W, Cout, KH, KW, stride, pad);
     MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
                 "miq_conv2d_i8: needs %zu bytes of workspace (got %zu)", need, workspace_bytes);
     MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_i8: workspace must be 256-byte aligned");
@@ -1864,6 +1891,11 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
 
     int8_t* xp = static_cast<int8_t*>(workspace);
     int8_t* wp = xp + miq::round_up(G.xp_bytes, 256);
+    if (prepacked) {   // the form this geometry's kernel stages from, inside the caller's packed weight
+        MIQ_REQUIRE(miq::aligned(w, 16), MIQ_EALIGN, "miq_conv2d_i8_prepacked: the packed weight must be 16-byte aligned");
+        const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
+        wp = const_cast<int8_t*>(w) + (G.planar ? pw.planar_at : 0);
+    }
 
     // 3 x 3 / stride 1 layers whose rows are whole dwords: the patch kernel stages the NCHW activation itself (no padded
     // copy, no re-layout launch); only the filters are re-laid, into the workspace.
@@ -1879,7 +1911,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             Cin == 64) {   // (one input-channel group: with more, the staging work costs what the re-layout launch did)
             const uint32_t wtotal = static_cast<uint32_t>(G.wp_bytes / 4);
             const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
-            if (!dev_switch("MIQ_CONV_SKIP_WPACK"))   // timing-only: the workspace still holds the last call's filters
+            if (!prepacked && !dev_switch("MIQ_CONV_SKIP_WPACK"))   // (the switch: timing-only, the workspace still holds the last call's filters)
                 pack_conv_weight_planar_kernel<<<wgrid, 256, 0, st>>>(w, wp, wtotal, (int)Cin, (int)Cout);
             if (int rc = miq::check_launch("pack_conv_weight_planar_kernel")) return rc;
             PlanarArgs pa{};
@@ -1922,7 +1954,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.Cout = (int)Cout;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.pitch + 2 * pad * H));
-            pa.weight_total = dev_switch("MIQ_CONV_SKIP_WPACK") ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
+            pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
@@ -1943,7 +1975,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
             pa.KH = (int)KH; pa.KW = (int)KW; pa.L = (int)G.L; pa.Lp = (int)G.Lp;
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
-            pa.weight_total = dev_switch("MIQ_CONV_SKIP_WPACK") ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
+            pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             pa.sub = (int)G.sub; pa.Ws = (int)G.Ws; pa.HWs = (int)(G.Hs * G.Ws);
             // about four border pixels / weight dwords per extra thread, spread over the images' grid rows
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
@@ -1962,7 +1994,7 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
                                                   (int)pad, cblocks);
         }
         if (int rc = miq::check_launch("nhwc re-layout kernel")) return rc;
-        if (!packed) {
+        if (!packed && !prepacked) {
             const uint32_t total = static_cast<uint32_t>(G.wp_bytes / 4);   // dwords
             const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
             pack_conv_weight_kernel<<<wgrid, 256, 0, st>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)G.Cp, (int)G.L,
@@ -2031,6 +2063,29 @@ extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_
         default:
             return launch<kOutI32>(a, st);
     }
+}
+
+extern "C" int miq_conv2d_i8(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    return conv2d_i8_run(false, x, w, B, Cin, H, W, Cout, KH, KW, stride, pad, bias, alpha, beta, out, out_dtype, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" size_t miq_conv2d_i8_prepacked_workspace(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t KH,
+                                                    int64_t KW, int64_t stride, int64_t pad) {
+    ConvGeom g;
+    if (!make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, g)) return 0;
+    return static_cast<size_t>(miq::round_up(g.xp_bytes, 256));
+}
+
+extern "C" int miq_conv2d_i8_prepacked(const int8_t* x, const int8_t* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                                       int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                                       const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return conv2d_i8_run(true, x, wp, B, Cin, H, W, Cout, KH, KW, stride, pad, bias, alpha, beta, out, out_dtype, workspace,
+                         workspace_bytes, stream);
 }
 
 // ---- dense layers with a stride / padding per axis or a dilation ----------------------------------------
@@ -2166,28 +2221,6 @@ int conv2d_i8_dense(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, in
 }  // namespace miq
 
 // ---- channels-last entry points ---------------------------------------------------------------------
-// The packed weight of the channels-last entry point: the im2col-order form wp[Cout][KH][Lp] and, for 3 x 3 filters over
-// whole 64-channel groups, behind it (at the next multiple of 256 bytes) the form conv3x3_patch_kernel stages from.
-struct PackedWeight {
-    int64_t rows_bytes;     // the im2col-order form
-    int64_t planar_at;      // offset of the patch kernel's form; 0 = none
-    int64_t planar_bytes;
-    int64_t total;
-};
-
-PackedWeight packed_weight_layout(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
-    PackedWeight pw{};
-    const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
-    pw.rows_bytes = Cout * KH * Lp;
-    pw.total = pw.rows_bytes;
-    if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0) {
-        pw.planar_at = miq::round_up(pw.rows_bytes, 256);
-        pw.planar_bytes = (Cout / 64) * (Cin / 64) * kWStageBytes;
-        pw.total = pw.planar_at + pw.planar_bytes;
-    }
-    return pw;
-}
-
 extern "C" size_t miq_conv2d_i8_packed_weight_bytes(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
     return static_cast<size_t>(packed_weight_layout(Cin, Cout, KH, KW).total);
@@ -2246,7 +2279,7 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
     // tiles are mostly pixels and the patch fits (the conditions of the NCHW entry point, with the caller's row
     // pitch Wp in place of the workspace's).
     const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
-    if (pw.planar_at && stride == 1 && G.M >= 4 * kTM && miq::aligned(out, 16) && miq::aligned(alpha, 16) &&
+    if (pw.planar_at && Cout % 64 == 0 && stride == 1 && G.M >= 4 * kTM && miq::aligned(out, 16) && miq::aligned(alpha, 16) &&
         miq::aligned(bias, 16) && !(dev_switch("MIQ_CONV_PLANAR") && dev_switch("MIQ_CONV_PLANAR")[0] == '0')) {
         const int64_t HoWo = G.Ho * G.Wo;
         int64_t group = 1;

@@ -1536,15 +1536,17 @@ int launch_patch_w8(const PatchW8Args& a, bool stream_out, hipStream_t st) {
 // up to 256) + wp_bytes.
 int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
                  int64_t Cout, int64_t pad, const float* bias, const float* alpha, float beta, void* out, int out_dtype,
-                 void* workspace, hipStream_t st) {
+                 void* workspace, hipStream_t st, const void* wp_packed = nullptr) {
     const int planes = conv_w8_planes(x_dtype);
     uint16_t* xp = static_cast<uint16_t*>(workspace);
-    uint4* wp = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
+    // the filters in the kernel's form: re-laid by this call behind the planes, or handed over already packed
+    uint4* wp = wp_packed ? static_cast<uint4*>(const_cast<void*>(wp_packed))
+                          : reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
     const int64_t items = (Cin / 8) * P.ptot;   // one thread per channel octet and padded pixel
     MIQ_REQUIRE(items < (1ll << 32), MIQ_ERANGE, "miq_conv2d_w8: too many padded pixels for the chunk-plane re-layout");
     const int pgrid = static_cast<int>(std::min<int64_t>(ceil_div(items, 256), 1 << 20));
     const uint32_t wtotal = static_cast<uint32_t>(P.wp_bytes / kChunk);
-    const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
+    const int wgrid = wp_packed ? 0 : static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
 #define MIQ_PATCH_PREP(T, NP)                                                                                                  \
     patch_w8_prep_kernel<T, NP><<<pgrid + wgrid, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp, \
                                                                (int)P.pitch, (int)pad, (uint32_t)P.ptot, (uint32_t)items, pgrid, w, \
@@ -1812,12 +1814,13 @@ StemW8Geom make_stem_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64
 
 int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
                 int64_t Cout, int64_t KH, int64_t KW, int64_t pad, const float* bias, const float* alpha, float beta, void* out,
-                int out_dtype, void* workspace, hipStream_t st) {
+                int out_dtype, void* workspace, hipStream_t st, const void* wp_packed = nullptr) {
     uint4* xp = static_cast<uint4*>(workspace);
-    uint4* wp = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
+    uint4* wp = wp_packed ? static_cast<uint4*>(const_cast<void*>(wp_packed))
+                          : reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
     const uint32_t npix = static_cast<uint32_t>(P.xp_bytes / kChunk), wchunks = static_cast<uint32_t>(P.wp_bytes / kChunk);
     const int n_prep = static_cast<int>(std::min<int64_t>(ceil_div(npix, 256), 1 << 20));
-    const int n_pack = static_cast<int>(std::min<int64_t>(ceil_div(wchunks, 256), 4096));
+    const int n_pack = wp_packed ? 0 : static_cast<int>(std::min<int64_t>(ceil_div(wchunks, 256), 4096));
 #define MIQ_STEM_PREP(T, NP)                                                                                               \
     stem_w8_prep_kernel<T, NP><<<n_prep + n_pack, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp, \
                                                                 (int)P.Wp, (int)pad, npix, n_prep, w, wp, wchunks, (int)Cout, \
@@ -1936,7 +1939,7 @@ extern "C" int miq_gemm_w8(const void* x, int x_dtype, const int8_t* W, int64_t 
 // order inside a run of kw_run taps), in one launch where the weight re-layout can ride along.  G.H / G.W / G.sub describe
 // the (possibly subsampled) image; rows x kw_run = the filter's taps.
 static int conv_w8_relayout(const void* x, int x_dtype, const int8_t* w, uint16_t* xp, int8_t* wp, const ConvW8Geom& G, int64_t B,
-                     int64_t Cin, int64_t Cout, int64_t rows, int64_t kw_run, int64_t pad, hipStream_t st) {
+                     int64_t Cin, int64_t Cout, int64_t rows, int64_t kw_run, int64_t pad, hipStream_t st, bool skip_weight = false) {
     const int64_t H = G.H, W = G.W;
     const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2;
     const uint32_t npix = static_cast<uint32_t>(B * G.Hp * G.Wp);
@@ -1945,7 +1948,7 @@ static int conv_w8_relayout(const void* x, int x_dtype, const int8_t* w, uint16_
     const int n_border = static_cast<int>(ceil_div((2 * pad * G.Wp + 2 * pad * H) * (G.Cp / 8), 256));
     const uint32_t wtotal = static_cast<uint32_t>(Cout * G.K);
     // about four weight bytes per thread, spread over the images
-    const bool pack_along = G.Cp > 16;
+    const bool pack_along = G.Cp > 16 && !skip_weight;
     ConvW8PackArgs pk{w, wp, wtotal, 0, (int)rows, (int)kw_run, (int)G.L, (int)G.Lp};
     if (pack_along) pk.n_wpack = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(ceil_div(wtotal, 1024), B), 1), 4096));
     const int64_t pblocks = B * (static_cast<int64_t>(n_interior) + n_border + pk.n_wpack);
@@ -1986,7 +1989,7 @@ static int conv_w8_relayout(const void* x, int x_dtype, const int8_t* w, uint16_
         MIQ_PREP(__bf16, 1);
 #undef MIQ_PREP
     if (int rc = check_launch("conv_w8_prep_x_kernel")) return rc;
-    if (!pack_along) {
+    if (!pack_along && !skip_weight) {
         conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
             w, wp, wtotal, (int)Cin, (int)rows, (int)kw_run, (int)G.Cp, (int)G.L, (int)G.Lp);
         if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
@@ -2005,10 +2008,103 @@ extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, i
     return static_cast<size_t>(conv_w8_planes(x_dtype) * G.plane_bytes + G.wp_bytes);
 }
 
-extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
-                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
-                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+extern "C" size_t miq_conv2d_w8_prepacked_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                                    int64_t KH, int64_t KW, int64_t stride, int64_t pad) {
+    ConvW8Geom G;
+    if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
+    const PatchW8Geom P = make_patch_w8_geom(conv_w8_planes(x_dtype), B, Cin, H, W, Cout, KH, KW, stride, pad);
+    if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256));
+    const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    if (S.ok) return static_cast<size_t>(round_up(S.xp_bytes, 256));
+    return static_cast<size_t>(conv_w8_planes(x_dtype) * G.plane_bytes);
+}
+
+// The packed weight of miq_conv2d_w8_pack_weight for activations of type x_dtype: the forms the three kernels stage from,
+// each at a multiple of 256 bytes.  It depends on the filter's shape and the activation type only.
+struct W8Packed {
+    int64_t rows_bytes;               // wp[Cout][KH][Lp]: the im2col-order kernel
+    int64_t patch_at, patch_bytes;    // conv3x3_patch_w8_kernel's widened filters (3 x 3 over whole 32-channel groups); 0 = none
+    int64_t stem_at, stem_bytes;      // conv_stem_w8_kernel's (at most 4 input channels, 5-8 columns, at most 7 rows); 0 = none
+    int64_t total;
+};
+
+static W8Packed w8_packed_layout(int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
+    W8Packed p{};
+    const int64_t Cp = round_up(Cin, 8), Lp = round_up(KW * Cp, 16);
+    p.rows_bytes = round_up(Cout * KH * Lp, 256);
+    p.total = p.rows_bytes;
+    const int planes = conv_w8_planes(x_dtype);
+    if (KH == 3 && KW == 3 && Cin % 32 == 0) {
+        p.patch_at = p.total;
+        p.patch_bytes = ceil_div(Cout, 64) * (Cin / (planes == 1 ? 32 : 16)) * (9 * (planes == 1 ? 4 : 2) * 64 * kChunk);
+        p.total += round_up(p.patch_bytes, 256);
+    }
+    if (Cin <= 4 && KW >= 5 && KW <= 8 && KH <= 7) {
+        p.stem_at = p.total;
+        p.stem_bytes = ceil_div(Cout, 64) * 2 * KH * 4 * 64 * kChunk;
+        p.total += round_up(p.stem_bytes, 256);
+    }
+    return p;
+}
+
+extern "C" size_t miq_conv2d_w8_packed_weight_bytes(int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
+    if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+    return static_cast<size_t>(w8_packed_layout(x_dtype, Cin, Cout, KH, KW).total);
+}
+
+extern "C" int miq_conv2d_w8_pack_weight(const int8_t* w, int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, void* wp,
+                                         void* stream) {
+    MIQ_REQUIRE(Cin > 0 && Cout >= 0 && KH > 0 && KW > 0, MIQ_EINVAL, "miq_conv2d_w8_pack_weight: bad shape");
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_conv2d_w8_pack_weight: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    if (Cout == 0) return MIQ_OK;
+    MIQ_REQUIRE(w && wp, MIQ_EINVAL, "miq_conv2d_w8_pack_weight: null pointer");
+    MIQ_REQUIRE(miq::aligned(wp, 256), MIQ_EALIGN, "miq_conv2d_w8_pack_weight: wp must be 256-byte aligned");
+    const W8Packed L = w8_packed_layout(x_dtype, Cin, Cout, KH, KW);
+    MIQ_REQUIRE(L.total < (1ll << 31), MIQ_ERANGE, "miq_conv2d_w8_pack_weight: packed weight beyond 2 GiB");
+    hipStream_t st = miq::as_stream(stream);
+    char* base = static_cast<char*>(wp);
+    {
+        const int64_t Cp = round_up(Cin, 8), Lrun = KW * Cp, Lp = round_up(Lrun, 16);
+        const uint32_t wtotal = static_cast<uint32_t>(Cout * KH * Lp);
+        conv_w8_pack_w_kernel<<<static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096), 256, 0, st>>>(
+            w, reinterpret_cast<int8_t*>(base), wtotal, (int)Cin, (int)KH, (int)KW, (int)Cp, (int)Lrun, (int)Lp);
+        if (int rc = check_launch("conv_w8_pack_w_kernel")) return rc;
+    }
+    if (L.patch_at) {
+        const uint32_t wtotal = static_cast<uint32_t>(L.patch_bytes / kChunk);
+        const int wgrid = static_cast<int>(wtotal / 256 + 1 < 4096 ? wtotal / 256 + 1 : 4096);
+        uint4* dst = reinterpret_cast<uint4*>(base + L.patch_at);
+        // (the activation half of the kernel gets no workgroups: n_prep = 0)
+        if (x_dtype == MIQ_F32)
+            patch_w8_prep_kernel<float, 2><<<wgrid, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 0, 1, 0, 1u, 0u, 0, w, dst, wtotal, (int)Cout);
+        else if (x_dtype == MIQ_F16)
+            patch_w8_prep_kernel<_Float16, 1><<<wgrid, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 0, 1, 0, 1u, 0u, 0, w, dst, wtotal, (int)Cout);
+        else
+            patch_w8_prep_kernel<__bf16, 1><<<wgrid, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 0, 1, 0, 1u, 0u, 0, w, dst, wtotal, (int)Cout);
+        if (int rc = check_launch("patch_w8_prep_kernel (filters)")) return rc;
+    }
+    if (L.stem_at) {
+        const uint32_t wchunks = static_cast<uint32_t>(L.stem_bytes / kChunk);
+        const int n_pack = static_cast<int>(std::min<int64_t>(ceil_div(wchunks, 256), 4096));
+        uint4* dst = reinterpret_cast<uint4*>(base + L.stem_at);
+        if (x_dtype == MIQ_F32)
+            stem_w8_prep_kernel<float, 2><<<n_pack, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 1, 1, 0, 0u, 0, w, dst, wchunks, (int)Cout, (int)KH, (int)KW);
+        else if (x_dtype == MIQ_F16)
+            stem_w8_prep_kernel<_Float16, 1><<<n_pack, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 1, 1, 0, 0u, 0, w, dst, wchunks, (int)Cout, (int)KH, (int)KW);
+        else
+            stem_w8_prep_kernel<__bf16, 1><<<n_pack, 256, 0, st>>>(nullptr, nullptr, (int)Cin, 0, 0, 1, 1, 0, 0u, 0, w, dst, wchunks, (int)Cout, (int)KH, (int)KW);
+        if (int rc = check_launch("stem_w8_prep_kernel (filters)")) return rc;
+    }
+    return MIQ_OK;
+}
+
+// `w` is the OIHW filter (prepacked = false: re-laid by this call into the workspace, behind the activation planes) or the
+// packed weight of miq_conv2d_w8_pack_weight for this x_dtype (prepacked = true: the workspace holds the planes only).
+static int conv2d_w8_run(bool prepacked, const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                         int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                         const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                         size_t workspace_bytes, void* stream) {
     ConvW8Geom G;
     MIQ_REQUIRE(make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G), MIQ_EINVAL,
                 "miq_conv2d_w8: bad geometry (B=%lld Cin=%lld H=%lld W=%lld Cout=%lld KH=%lld KW=%lld stride=%lld pad=%lld)",
@@ -2027,11 +2123,15 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2, esz = out_dtype == MIQ_BF16 ? 2 : 4;
     MIQ_REQUIRE(miq::aligned(x, xsz) && miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
                 "miq_conv2d_w8: x/out/alpha/bias not aligned to their element size");
-    const size_t need = miq_conv2d_w8_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, stride, pad);
+    const size_t need = prepacked ? miq_conv2d_w8_prepacked_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, stride, pad)
+                                  : miq_conv2d_w8_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, stride, pad);
     MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE, "miq_conv2d_w8: needs %zu bytes of workspace (got %zu)",
                 need, workspace_bytes);
     MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_conv2d_w8: workspace must be 256-byte aligned");
     hipStream_t st = miq::as_stream(stream);
+    const W8Packed PK = w8_packed_layout(x_dtype, Cin, Cout, KH, KW);
+    const char* packed = reinterpret_cast<const char*>(w);
+    if (prepacked) MIQ_REQUIRE(miq::aligned(w, 256), MIQ_EALIGN, "miq_conv2d_w8_prepacked: the packed weight must be 256-byte aligned");
     // 3 x 3 / stride 1 over whole 32-channel groups: the kernel that keeps a tile's pixel patch in LDS (16-byte stores
     // of four fp32 pixels / 8-byte stores of four bf16 pixels need the output aligned to them)
     {
@@ -2039,7 +2139,8 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
         if (P.ok) {
             MIQ_REQUIRE((P.Ho * P.Wo) % 4 != 0 || miq::aligned(out, 4 * esz), MIQ_EALIGN,
                         "miq_conv2d_w8: out must be aligned to four of its elements");
-            return run_patch_w8(P, x, x_dtype, w, B, Cin, H, W, Cout, pad, bias, alpha, beta, out, out_dtype, workspace, st);
+            return run_patch_w8(P, x, x_dtype, w, B, Cin, H, W, Cout, pad, bias, alpha, beta, out, out_dtype, workspace, st,
+                                prepacked ? packed + PK.patch_at : nullptr);
         }
     }
     // stems (at most four input channels, 5-8 filter columns, stride 2) whose output rows are whole 16-byte vectors
@@ -2047,14 +2148,15 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
         const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
         if (S.ok) {
             MIQ_REQUIRE(miq::aligned(out, 4 * esz), MIQ_EALIGN, "miq_conv2d_w8: out must be aligned to four of its elements");
-            return run_stem_w8(S, x, x_dtype, w, B, Cin, H, W, Cout, KH, KW, pad, bias, alpha, beta, out, out_dtype, workspace, st);
+            return run_stem_w8(S, x, x_dtype, w, B, Cin, H, W, Cout, KH, KW, pad, bias, alpha, beta, out, out_dtype, workspace, st,
+                               prepacked ? packed + PK.stem_at : nullptr);
         }
     }
     H = G.H; W = G.W; stride = G.stride;   // a subsampled 1 x 1 layer continues as its stride-1 equivalent
 
     uint16_t* xp = static_cast<uint16_t*>(workspace);
-    int8_t* wp = static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
-    if (int rc = conv_w8_relayout(x, x_dtype, w, xp, wp, G, B, Cin, Cout, KH, KW, pad, st)) return rc;
+    int8_t* wp = prepacked ? reinterpret_cast<int8_t*>(const_cast<char*>(packed)) : static_cast<int8_t*>(workspace) + planes * G.plane_bytes;
+    if (int rc = conv_w8_relayout(x, x_dtype, w, xp, wp, G, B, Cin, Cout, KH, KW, pad, st, prepacked)) return rc;
 
     W8fArgs g{xp, wp, bias, alpha, out, beta, static_cast<int>(G.M), static_cast<int>(Cout), static_cast<int>(G.K),
               static_cast<uint32_t>(G.plane_bytes), 0, 0, 0,
@@ -2066,6 +2168,22 @@ extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_
     if (x_dtype == MIQ_F16)
         return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32, true>(g, st) : launch_conv_w8f_np<1, kOutBF16, true>(g, st);
     return out_dtype == MIQ_F32 ? launch_conv_w8f_np<1, kOutF32>(g, st) : launch_conv_w8f_np<1, kOutBF16>(g, st);
+}
+
+extern "C" int miq_conv2d_w8(const void* x, int x_dtype, const int8_t* w, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                             int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                             const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    return conv2d_w8_run(false, x, x_dtype, w, B, Cin, H, W, Cout, KH, KW, stride, pad, bias, alpha, beta, out, out_dtype,
+                         workspace, workspace_bytes, stream);
+}
+
+extern "C" int miq_conv2d_w8_prepacked(const void* x, int x_dtype, const void* wp, int64_t B, int64_t Cin, int64_t H, int64_t W,
+                                       int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, const float* bias,
+                                       const float* alpha, float beta, void* out, int out_dtype, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return conv2d_w8_run(true, x, x_dtype, static_cast<const int8_t*>(wp), B, Cin, H, W, Cout, KH, KW, stride, pad, bias, alpha,
+                         beta, out, out_dtype, workspace, workspace_bytes, stream);
 }
 
 // ---- dense layers with a stride / padding per axis or a dilation ----------------------------------------

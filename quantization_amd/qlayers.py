@@ -60,6 +60,7 @@ class _QuantizerBase(nn.Module):
         self.register_buffer("weight", torch.zeros(self.weight_shape, dtype=torch.int8))
         self._gpu_cache = {}      # device copies of host-resident weight / bias / scales, keyed by role
         self._beta_cache = None   # (output_zero_point tensor, its version, the value as a Python float)
+        self._packed_cache = {}   # activation dtype -> (weight tensor, its version, packed filter): see _packed()
         self._params_stale = None # set to a message when a checkpoint without quantization parameters was loaded
 
     def to(self, *args, **kwargs):
@@ -73,6 +74,26 @@ class _QuantizerBase(nn.Module):
     def _invalidate(self):
         self._gpu_cache = {}
         self._beta_cache = None
+        self._packed_cache = {}
+
+    def _packed(self, w, act_dtype):
+        """The Conv2d filter in the form the MFMA kernels stage from (miq_conv2d_i8_pack_weight /
+        miq_conv2d_w8_pack_weight), made once per weight and activation type: the weight changes only in
+        from_float (quant/Weight_Only/Quantizer.py:93-112), so no forward re-lays it.  `w` is the weight on the GPU."""
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        ent = cache.get(act_dtype)
+        if ent is None or ent[0] is not w or ent[1] != w._version:
+            packed = (_native.conv2d_i8_pack_weight(w) if act_dtype == torch.int8
+                      else _native.conv2d_w8_pack_weight(w, act_dtype))
+            ent = cache[act_dtype] = (w, w._version, packed)
+        return ent[2]
+
+    def _prepack(self):
+        """from_float's last step for plain Conv2d layers whose weight is already on the GPU: the packed filters for int8
+        and fp32 activations (other activation types are packed on their first forward)."""
+        if self.cnn and self.weight.is_cuda and _plain_conv(self.stride, self.padding, self.dilation, self.groups):
+            self._packed(self.weight, torch.int8)
+            self._packed(self.weight, torch.float32)
 
     def _on_gpu(self, role, t):
         """`t` on the GPU.  A module kept on the host would otherwise upload its whole int8 weight (and bias,
@@ -110,20 +131,33 @@ class _QuantizerBase(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
+        # A checkpoint the reference wrote holds the int8 weight without its scales.  The reference's own flow is Chunker
+        # on the pretrained float model, then load_state_dict of such a checkpoint of the SAME model: the incoming weight
+        # then equals the one this module's scales were computed for, and they stay valid.
+        incoming = state_dict.get(prefix + "weight")
+        same_weight = (isinstance(incoming, torch.Tensor) and incoming.shape == self.weight.shape
+                       and incoming.dtype == self.weight.dtype
+                       and bool(torch.equal(incoming.to(self.weight.device), self.weight)))
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
         self._invalidate()
         key = prefix + "_extra_state"
         if key in missing_keys:
-            # A checkpoint the reference wrote: the int8 weight without its scales.  It loads (the keys it has are
-            # the reference's), but the scales this module holds belong to OTHER weights: refuse to run with
-            # them until the caller supplies the parameters (set_extra_state / re-quantize / re-calibrate).
+            # It loads (the keys it has are the reference's); when the weight is a different one, the scales this module
+            # holds belong to OTHER weights: refuse to run with them until the caller supplies the parameters
+            # (set_extra_state / accept_current_quant_params / re-quantize / re-calibrate).
             missing_keys.remove(key)
-            if prefix + "weight" in state_dict:
+            if prefix + "weight" in state_dict and not same_weight:
                 self._params_stale = (f"{prefix or 'layer'}: the loaded state_dict carries an int8 weight but no "
                                       "quantization parameters (no '_extra_state' entry); the scales held by this "
                                       "module were computed from different weights")
                 warnings.warn(self._params_stale + " -- forward() will raise until they are set", stacklevel=2)
+
+    def accept_current_quant_params(self):
+        """Declare that the quantization parameters this module holds belong to the weight it now holds (after loading
+        a checkpoint that carries the int8 weight only): forward() runs again."""
+        self._params_stale = None
+        return self
 
     # ---- the two products -------------------------------------------------------------
     def _int8_product(self, x, bias, alpha, beta):
@@ -131,7 +165,7 @@ class _QuantizerBase(nn.Module):
         if self.cnn:
             if _plain_conv(self.stride, self.padding, self.dilation, self.groups):
                 return _native.conv2d_i8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha,
-                                         beta=beta)
+                                         beta=beta, packed=self._packed(w, torch.int8))
             return _native.conv2d_general(x, w, self.stride, self.padding, self.dilation, self.groups, bias=bias,
                                           alpha=alpha, beta=beta)
         lead = x.shape[:-1]
@@ -155,7 +189,8 @@ class _QuantizerBase(nn.Module):
         if not batched:   # F.conv2d also takes one image [C, H, W]
             x = x.unsqueeze(0)
         if _plain_conv(self.stride, self.padding, self.dilation, self.groups):
-            y = _native.conv2d_w8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha, beta=beta)
+            y = _native.conv2d_w8(x, w, _single(self.stride), _single(self.padding), bias=bias, alpha=alpha, beta=beta,
+                                  packed=self._packed(w, x.dtype))
         else:
             # ... and otherwise (dilation, groups, a stride / padding per axis, string padding) the direct convolution
             y = _native.conv2d_general(x, w, self.stride, self.padding, self.dilation, self.groups, bias=bias,
@@ -274,6 +309,7 @@ class WeightOnlyQuantizer(_QuantizerBase):
         new_module = cls(bias=module.bias, quantize_output=quantize_output, data_metrics=data_metry,
                                          activations=activations, **_layer_kwargs(module))
         new_module.weight = new_module.weight_quant.quantize(module.weight)
+        new_module._prepack()
         return new_module
 
     def __repr__(self):
@@ -386,6 +422,7 @@ class WeightActivationQuantizer(_QuantizerBase):
         )
         new_module.weight = weight_quant.quantize(module.weight)
         new_module.weight_qscale, new_module.weight_zero_point = weight_quant.scales, weight_quant.zero_point
+        new_module._prepack()
         return new_module
 
     def __repr__(self):

@@ -34,7 +34,12 @@ def check(N, B, C, H, W, Co, k, s, p, xdt, seed, bias=True, out_dtype=torch.floa
     b = torch.randn(Co, generator=g) * 5 if bias else None
     y = N.conv2d_w8(x.cuda(), w.cuda(), s, p, bias=None if b is None else b.cuda(), alpha=alpha.cuda(), beta=beta,
                     out_dtype=out_dtype)
+    # the same call with the filter packed once (miq_conv2d_w8_pack_weight + miq_conv2d_w8_prepacked): the same kernels
+    # on the same operands, so the results are equal bit for bit (and y is checked against the fp64 convolution below)
+    yp = N.conv2d_w8(x.cuda(), w.cuda(), s, p, bias=None if b is None else b.cuda(), alpha=alpha.cuda(), beta=beta,
+                     out_dtype=out_dtype, packed=N.conv2d_w8_pack_weight(w.cuda(), DT[xdt]))
     torch.cuda.synchronize()
+    assert torch.equal(y, yp), "prepacked filter: result differs from the call that packs its own"
     xd, wd = x.double(), w.double()
     bd = torch.zeros(Co, dtype=torch.float64) if b is None else b.double()
     a4 = alpha.double().view(1, -1, 1, 1)

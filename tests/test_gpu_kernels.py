@@ -293,6 +293,11 @@ def test_conv_i32_bit_exact(N, B, C, H, W, Co, k, s, p):
     out = N.conv2d_i8(x.cuda(), w.cuda(), s, p, out_dtype=torch.int32)
     assert out.shape == ref.shape
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # the same layer with its filter packed once (miq_conv2d_i8_pack_weight + miq_conv2d_i8_prepacked), against the oracle
+    wd = w.cuda()
+    packed = N.conv2d_i8_pack_weight(wd)
+    out2 = N.conv2d_i8(x.cuda(), wd, s, p, out_dtype=torch.int32, packed=packed)
+    np.testing.assert_array_equal(out2.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("B,C,H,W,Co,pad,shift", [(3, 64, 56, 56, 64, 1, 4), (8, 64, 30, 28, 64, 0, 4), (8, 64, 30, 28, 70, 1, 12),
@@ -372,6 +377,9 @@ def test_conv_epilogue_bit_exact_vs_oracle(N, B, C, H, W, Co, k, s, p):
     ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), -1.25)
     out = N.conv2d_i8(x.cuda(), w.cuda(), s, p, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    outp = N.conv2d_i8(x.cuda(), w.cuda(), s, p, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25,
+                       packed=N.conv2d_i8_pack_weight(w.cuda()))
+    np.testing.assert_array_equal(outp.cpu().numpy(), ref)
     outb = N.conv2d_i8(x.cuda(), w.cuda(), s, p, bias=bias.cuda(), alpha=alpha.cuda(), beta=-1.25,
                        out_dtype=torch.bfloat16)
     np.testing.assert_array_equal(outb.float().cpu().numpy(), O.round_f32_to_bf16(ref))
