@@ -197,7 +197,7 @@ def llama8b_mlp_decode(N_, dev):
         nbytes = 3 * 14336 * 4096 + M * (2 * 4096 + 14336) + 4 * M * (2 * 14336 + 4096)
         res[f"M{M}"] = {"step_ms": round(ms, 4), "step_ms_enqueued_from_python": round(eager, 4),
                         "weight_GBps": round(3 * 14336 * 4096 / (ms * 1e-3) / 1e9, 1), "roofline": hbm_roofline(nbytes, ms),
-                        "fused_gate_up": {"step_ms": round(fused, 4), "roofline": hbm_roofline(nbytes - M * 4096, fused)}}
+                        "fused": {"step_ms": round(fused, 4), "roofline": hbm_roofline(nbytes - M * 4096, fused)}}
     return res
 
 
@@ -518,11 +518,10 @@ def cpu_baseline(K, N, sample_rows, seed):
         "unit": "TOPS",
         "cores": threads,
         "kind": "port",
-        "sample": f"WO forward, {sample_rows} of {N} rows x full [{N},{K}] int8 weight (float GEMM + weight cast), median of 5; "
-                  f"moves +-30% run to run",
+        "sample": f"WO forward {sample_rows}x[{N},{K}] (float GEMM + weight cast), median of 5 (+-30% box to box)",
         "spread": [round(2.0 * sample_rows * N * K / t / 1e12, 3) for t in (max(times), min(times))],
         "quantizer_GBps": round((14336 * 4096 * 5 + 14336 * 12) / tq / 1e9, 3),
-        "quantizer_sample": "Qop.quantize of the full fp32 [14336,4096] (per-row Python loop), median of 3",
+        "quantizer_sample": "Qop.quantize fp32 [14336,4096], row loop, median of 3",
     }
 
 
@@ -717,7 +716,7 @@ def main():
         out_name = {"f32": "float32", "bf16": "bfloat16", "i8": "int8 (requantised in the epilogue)"}[gather_name]
         q_roof = hbm_roofline(q_bytes, q_ms)
         line = {
-            "metric": "int8 linear TOPS (M=N=K=8192, fused per-channel dequant epilogue)",
+            "metric": "int8 linear TOPS (M=N=K=8192, fused per-channel dequant epilogue)" if S == 8192 else f"int8 linear TOPS (M=N=K={S})",
             "value": round(value, 1),
             "unit": "TOPS",
             "n_gpus": world,
@@ -730,12 +729,10 @@ def main():
             "dtype": "int8",
             "data": "synthetic",
             "config": {
-                "workload": f"int8 linear M={M} N={S}/GPU K={K}: int8 x per-channel int8 -> int32 MFMA -> (acc+bias)*scale, {out_name} out"
-                            + ("" if world == 1 else f"; x{world} column shards + in-place all-gather"),
-                "M": M, "N_per_gpu": S, "K": K, "out_dtype": out_name,
+                "workload": f"int8 linear M={M} N={S}/GPU K={K}, int8 x int8 -> i32 MFMA -> (acc+bias)*scale -> {out_name}"
+                            + ("" if world == 1 else f"; x{world} column shards + all-gather"),
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world} + all-gather ({gather_name})",
                 "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
-                "prewarm_s": PREWARM_S,
             },
             "roofline": {
                 "bound": "mfma",
@@ -746,14 +743,12 @@ def main():
                 "traffic": profiled_traffic("gemm_i8_256_kernel") if S == 8192 else None,
                 "kernel": "gemm_i8_256_kernel",
                 "kernel_ms": round(k_ms, 4),
-                "kernel_ms_event_pairs": round(pair_ms, 4),
-                "kernel_ms_region": round(region_ms, 4),
                 "quantizer": {"shape": f"fp32 [{QR},{QC}]", "GBps": q_roof["achieved"], "frac": q_roof["frac"],
                               "kernel_ms": round(q_ms, 4), "bytes": q_bytes,
                               "traffic": profiled_traffic("quantize_rows_reg_kernel") if S == 8192 else None},
             },
         }
-        extra = {"prewarm_s": PREWARM_S,
+        extra = {"prewarm_s": PREWARM_S, "kernel_ms_event_pairs": round(pair_ms, 4), "kernel_ms_region": round(region_ms, 4),
                  "quantizer": {"workload": f"per-channel symmetric int8 quantize of fp32 [{QR},{QC}] (5 B/element + 12 B/row)",
                                "kernel_ms": round(q_ms, 4), "roofline": q_roof}}
         extra.update(extras)
@@ -768,17 +763,19 @@ def main():
             extra["activation_quantizer"] = activation_quantizer(N_, dev)
             # one number per other configuration, inside the record the driver keeps
             qs, go, dec = extra["quantizer_shapes"], extra["gemm_other_shapes"], extra["llama3_8b_mlp_decode"]
-            line["roofline"]["others"] = {
-                "quantizer_frac": {k: v["roofline"]["frac"] for k, v in qs.items()},
-                "gemm_frac": {k: v["roofline"]["frac"] for k, v in go.items()},
-                "decode_mlp_frac": {m: dec[m]["roofline"]["frac"] for m in ("M1", "M16")},
-                "decode_mlp_fused_frac": {m: dec[m]["fused_gate_up"]["roofline"]["frac"] for m in ("M1", "M16")},
-                "conv_int8_stack_ms": extra["conv_int8"]["stack"]["total_ms"],
-                "conv_int8_stack_roofline_frac": extra["conv_int8"]["stack"]["frac_of_summed_layer_rooflines"],
-                "conv_int8_nhwc_stack_ms": extra["conv_int8"]["stack_channels_last_int8"]["total_ms"],
-                "conv_w8_stack_ms": {k.replace("stack_", ""): v["total_ms"] for k, v in extra["conv_weight_only_float"].items()
-                                     if k.startswith("stack_")},
-                "dynamic_w8a8_M16_ms": extra["activation_quantizer"]["linear_dynamic_w8a8_M16_[14336,4096]"]["call_ms"],
+            short = {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}
+            cw = extra["conv_weight_only_float"]
+            line["roofline"]["others"] = {   # fractions of the bound named in bench_extra.json; times in ms
+                "quant": {k.replace("_float32", "").replace("_bfloat16", "bf16"): v["roofline"]["frac"] for k, v in qs.items()},
+                "gemm": {k.split("x")[0] + "^3_" + short[k.split("_")[1]]: v["roofline"]["frac"] for k, v in go.items()},
+                "decode": {m: dec[m]["roofline"]["frac"] for m in ("M1", "M16")},
+                "decode_fused": {m: dec[m]["fused"]["roofline"]["frac"] for m in ("M1", "M16")},
+                "conv_i8_ms": extra["conv_int8"]["stack"]["total_ms"],
+                "conv_i8_frac": extra["conv_int8"]["stack"]["frac_of_summed_layer_rooflines"],
+                "conv_i8_nhwc_ms": extra["conv_int8"]["stack_channels_last_int8"]["total_ms"],
+                "conv_w8_ms": {short[k.replace("stack_", "")]: v["total_ms"] for k, v in cw.items() if k.startswith("stack_")},
+                "conv_w8_f32_frac": cw["stack_float32"]["frac_of_summed_layer_rooflines"],
+                "dyn_w8a8_M16_ms": extra["activation_quantizer"]["linear_dynamic_w8a8_M16_[14336,4096]"]["call_ms"],
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, S, 1024, 7)

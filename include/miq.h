@@ -39,6 +39,7 @@ extern "C" {
 #define MIQ_F16 1
 #define MIQ_BF16 2
 #define MIQ_I32 3 /* outputs only: raw accumulators, no epilogue */
+#define MIQ_I8 4  /* int8 activations in; as an output only of miq_conv2d_i8_nhwc and miq_gemm_i8_ex */
 
 /* layout of the weight operand of miq_gemm_i8 */
 #define MIQ_W_NK 0 /* [N,K], K contiguous: what Quantizer.weight holds (Quantizer.py:33) */
@@ -122,6 +123,25 @@ size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K);
 int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
                 const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* miq_gemm_i8 with the output placed and typed as a column-sharded layer needs it (one rank of a layer split by output
+ * channel over the GPUs of a node computes out[:, lo:hi] and all-gathers the blocks; the reference has no multi-GPU
+ * code, and its single-GPU contract returns one row-major matrix, cuda_kernels/linear_int8/linear_w8a8.cpp:15-20):
+ *   out_layout MIQ_OUT_MN: out[m * ldo + n], ldo >= N: the rank's columns written straight into a wider row-major matrix.
+ *   out_layout MIQ_OUT_NM: out[n * ldo + m], ldo >= M: the TRANSPOSED result.  A rank's block is then rows lo..hi of one
+ *     [N_total, M] matrix, so the ranks' blocks are contiguous in rank order and a plain all-gather leaves the whole
+ *     (transposed) output dense, with no re-arranging pass.  bias / alpha are per output channel n as always.
+ *   out_dtype MIQ_I8 (besides those of miq_gemm_i8): out = int8(clamp(rint(y / requant_scale), -128, 127)) with
+ *     y = (acc + bias[n]) * alpha[n] + beta in fp32, IEEE division, round-half-even: the per-tensor form of Qop.quantize
+ *     (quant/Weight_Only/Qop.py:154-157) with a static activation scale, which is what a following int8 layer consumes;
+ *     a quarter of the fp32 bytes on the links.  requant_scale must be positive; other out_dtypes ignore it.
+ * Same arithmetic, kernels and workspace rules as miq_gemm_i8 (miq_gemm_i8_ex_workspace bytes). */
+#define MIQ_OUT_MN 0
+#define MIQ_OUT_NM 1
+size_t miq_gemm_i8_ex_workspace(int w_layout, int out_layout, int64_t M, int64_t N, int64_t K);
+int miq_gemm_i8_ex(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                   const float* bias, const float* alpha, float beta, void* out, int out_dtype, int out_layout,
+                   int64_t ldo, float requant_scale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* miq_gemm_i8 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and
@@ -286,7 +306,6 @@ int miq_conv2d_general(const void* x, int x_dtype, const int8_t* w, int64_t B, i
  * forwards (quant/Weight_Activation/Chunker.py:75-77).  The cast to int8 truncates toward zero
  * and wraps modulo 256 as the host's cast does (200.0 -> -56); NaN and |v| >= 2^31 give 0.
  */
-#define MIQ_I8 4 /* inputs; as an output only of miq_conv2d_i8_nhwc */
 #define MIQ_POOL_MAX 0
 #define MIQ_POOL_AVG 1
 int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw,

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmiq.so")
 MIQ_F32, MIQ_F16, MIQ_BF16, MIQ_I32, MIQ_I8 = 0, 1, 2, 3, 4
 MIQ_POOL_MAX, MIQ_POOL_AVG = 0, 1
 MIQ_W_NK, MIQ_W_KN = 0, 1
+MIQ_OUT_MN, MIQ_OUT_NM = 0, 1
 
 _FLOAT_CODES = {torch.float32: MIQ_F32, torch.float16: MIQ_F16, torch.bfloat16: MIQ_BF16}
 _OUT_CODES = {torch.float32: MIQ_F32, torch.bfloat16: MIQ_BF16, torch.int32: MIQ_I32}
@@ -38,6 +39,9 @@ SYMBOLS = {
     "miq_epilogue_channels_f32": (_int, [_p, _p, _p, ctypes.c_float, _i64, _i64, _i64, _p, _p]),
     "miq_gemm_i8_workspace": (_size, [_int, _i64, _i64, _i64]),
     "miq_gemm_i8": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p, _size, _p]),
+    "miq_gemm_i8_ex_workspace": (_size, [_int, _int, _i64, _i64, _i64]),
+    "miq_gemm_i8_ex": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _int, _i64, ctypes.c_float,
+                              _p, _size, _p]),
     "miq_gemm_i8_noalloc_max_workspace": (_size, []),
     "miq_gemm_i8_noalloc": (_int, [_p, _p, _int, _i64, _i64, _i64, _p, _p, ctypes.c_float, _p, _int, _p]),
     "miq_gemm_w8_workspace": (_size, [_int, _i64, _i64, _i64]),
@@ -294,8 +298,13 @@ def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):
     return out
 
 
-def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None):
-    """out[m,n] = (float(sum_k a[m,k]*w[n,k]) + bias[n]) * alpha[n] + beta, or the raw int32 sums."""
+def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=torch.float32, out=None,
+            transpose_out=False, requant_scale=1.0):
+    """out[m,n] = (float(sum_k a[m,k]*w[n,k]) + bias[n]) * alpha[n] + beta, or the raw int32 sums.
+
+    The forms a column-sharded layer uses (miq_gemm_i8_ex): `out` may be a column block of a wider row-major matrix (a 2-D
+    view with unit column stride); transpose_out=True writes the transposed result out[n, m] (shape [N, M]);
+    out_dtype=torch.int8 requantises, clamp(rint(y / requant_scale)) with the IEEE division of Qop.quantize."""
     require_device(a, "input")
     require_device(w, "weights")
     if a.dtype != torch.int8 or w.dtype != torch.int8:
@@ -309,22 +318,35 @@ def gemm_i8(a, w, w_layout=MIQ_W_NK, bias=None, alpha=None, beta=0.0, out_dtype=
         Kw, N = w.shape
     if K != Kw:
         raise RuntimeError(f"shape mismatch: input is [{M},{K}], weights contract over {Kw}")
-    if out_dtype not in _OUT_CODES:
+    if out_dtype not in _OUT_CODES_CL:
         raise RuntimeError(f"unsupported output dtype {out_dtype}")
     bias = _f32_vec(bias, N, "bias", a.device)
     alpha = _f32_vec(alpha, N, "alpha", a.device)
+    shape = (N, M) if transpose_out else (M, N)
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty(shape, dtype=out_dtype, device=a.device)
     else:
-        require_device(out, "out")
-        if out.shape != (M, N) or out.dtype != out_dtype:
-            raise RuntimeError("out has the wrong shape or dtype")
+        if not out.is_cuda:
+            raise RuntimeError("out must be a CUDA tensor")
+        if tuple(out.shape) != shape or out.dtype != out_dtype or out.device != a.device:
+            raise RuntimeError("out has the wrong shape, dtype or device")
+        if out.dim() != 2 or (out.numel() and (out.stride(1) != 1 or out.stride(0) < shape[1])):
+            raise RuntimeError("out must be dense or a column block of a row-major matrix (unit column stride)")
+    ldo = out.stride(0) if (out.numel() and shape[0] > 1) else shape[1]
     L = lib()
-    need = L.miq_gemm_i8_workspace(w_layout, M, N, K)
+    if not transpose_out and out_dtype != torch.int8 and ldo == shape[1]:
+        need = L.miq_gemm_i8_workspace(w_layout, M, N, K)
+        ws = torch.empty(need, dtype=torch.int8, device=a.device) if need else None
+        with _on(a.device):
+            _check(L.miq_gemm_i8(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
+                                 _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+        return out
+    layout = MIQ_OUT_NM if transpose_out else MIQ_OUT_MN
+    need = L.miq_gemm_i8_ex_workspace(w_layout, layout, M, N, K)
     ws = torch.empty(need, dtype=torch.int8, device=a.device) if need else None
     with _on(a.device):
-        _check(L.miq_gemm_i8(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
-                             _OUT_CODES[out_dtype], _ptr(ws), need, _stream()))
+        _check(L.miq_gemm_i8_ex(_ptr(a), _ptr(w), w_layout, M, N, K, _ptr(bias), _ptr(alpha), float(beta), _ptr(out),
+                                _OUT_CODES_CL[out_dtype], layout, ldo, float(requant_scale), _ptr(ws), need, _stream()))
     return out
 
 

@@ -117,6 +117,17 @@ __device__ __forceinline__ uint32_t requant4_i8(float a, float b, float c, float
     return lo | hi;
 }
 
+// One value requantised: the low byte of requant4_i8.
+__device__ __forceinline__ int8_t requant1_i8(float y) {
+#pragma clang fp contract(off)
+    const float r = __builtin_amdgcn_fmed3f(y, -128.0f, 127.0f) + 12582912.0f;
+    return static_cast<int8_t>(__float_as_uint(r) & 0xffu);
+}
+
+// The division of Qop.quantize's per-tensor form, round(y / scale) (quant/Weight_Only/Qop.py:155): IEEE, as the
+// reference's tensor / tensor division; a scale of exactly 1 leaves y as it is.
+__device__ __forceinline__ float requant_div(float y, float scale) { return scale == 1.0f ? y : __fdiv_rn(y, scale); }
+
 // dequant1 on two values at once, as packed fp32 instructions (one rounding per step, no contraction).
 __device__ __forceinline__ v2f dequant2(int a, int b, v2f bias, v2f alpha, v2f beta) {
 #pragma clang fp contract(off)
@@ -161,10 +172,16 @@ __device__ __forceinline__ float dequant1(float acc, float bias, float alpha, fl
 // row group (channels 0-15 and 16-31 of the wave's 32) first trade 16-lane rows (pair_rows_bf16); every
 // lane then stores eight consecutive channels as one 16-byte vector: half the store instructions, and a
 // row's 32 channels leave as one 64-byte segment.
-template <int OUT, bool NT = true, bool WIDE16 = true, int QN = 2, typename Args, typename V4>
+//
+// EXT (the int8 GEMM's argument block): g.by_row != 0 takes bias / alpha per output ROW m instead of per column n (the
+// transposed product of a column-sharded layer, whose rows are the output channels); OUT == kOutI8 requantises the
+// dequantised value, clamp(rint(y / g.out_div)), four consecutive columns as one dword.
+template <int OUT, bool NT = true, bool WIDE16 = true, int QN = 2, bool EXT = false, typename Args, typename V4>
 __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2][QN][4][2], int m0, int n0, int wm,
                                                int wn, int lane) {
     const bool vec_ok = (g.ldc & 3) == 0;
+    bool by_row = false;
+    if constexpr (EXT) by_row = g.by_row != 0;
 #pragma unroll
     for (int qn = 0; qn < QN; ++qn) {
         const int nb = n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
@@ -177,13 +194,31 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                 al[j][e] = 1.f;
                 bi[j][e] = 0.f;
                 if constexpr (OUT != kOutI32) {
-                    if (n + e < g.N) {
+                    if (!by_row && n + e < g.N) {
                         al[j][e] = g.alpha[n + e];
                         if (g.bias) bi[j][e] = g.bias[n + e];
                     }
                 }
             }
         }
+        // the parameters of output row m (by_row): one value for all of a lane's columns
+        auto row_params = [&](int m, float (&a4)[4], float (&b4)[4], int j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a4[e] = al[j][e];
+                b4[e] = bi[j][e];
+            }
+            if constexpr (EXT && OUT != kOutI32) {
+                if (by_row) {
+                    const float a = g.alpha[m], b = g.bias ? g.bias[m] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a4[e] = a;
+                        b4[e] = b;
+                    }
+                }
+            }
+        };
         if constexpr (OUT == kOutBF16 && WIDE16) {
             if ((g.ldc & 7) == 0 && nb + 32 <= g.N) {   // wave-uniform
                 const int n = nb + paired_offset(lane);
@@ -191,15 +226,18 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                 for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
+                        const int mc = m < g.M ? m : g.M - 1;   // (rows past the edge compute and trade, and store nothing)
                         uint2 p[2];
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const V4 a = acc[qm][qn][i][j];
-                            p[j] = pack4_bf16(dequant1(a[0], bi[j][0], al[j][0], g.beta), dequant1(a[1], bi[j][1], al[j][1], g.beta),
-                                              dequant1(a[2], bi[j][2], al[j][2], g.beta), dequant1(a[3], bi[j][3], al[j][3], g.beta));
+                            float a4[4], b4[4];
+                            row_params(mc, a4, b4, j);
+                            p[j] = pack4_bf16(dequant1(a[0], b4[0], a4[0], g.beta), dequant1(a[1], b4[1], a4[1], g.beta),
+                                              dequant1(a[2], b4[2], a4[2], g.beta), dequant1(a[3], b4[3], a4[3], g.beta));
                         }
                         const v4i v = pair_rows_bf16(p[0], p[1]);
-                        const int m = m0 + qm * 128 + wm * 64 + i * 16 + (lane & 15);
                         if (m >= g.M) continue;
                         v4i* o = reinterpret_cast<v4i*>(static_cast<uint16_t*>(g.out) + static_cast<size_t>(m) * g.ldc + n);
                         if constexpr (NT) {
@@ -236,9 +274,10 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                                 if (n + e < g.N) o[e] = a[e];
                         }
                     } else {
-                        float y[4];
+                        float y[4], a4[4], b4[4];
+                        row_params(m, a4, b4, j);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[j][e], al[j][e], g.beta);
+                        for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], b4[e], a4[e], g.beta);
                         if constexpr (OUT == kOutF32) {
                             float* o = static_cast<float*>(g.out) + idx;
                             if (vec_ok && n + 3 < g.N) {
@@ -254,6 +293,19 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
                                     if (n + e < g.N) o[e] = y[e];
+                            }
+                        } else if constexpr (OUT == kOutI8) {
+                            int8_t* o = static_cast<int8_t*>(g.out) + idx;
+                            float d = 1.0f;
+                            if constexpr (EXT) d = g.out_div;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = requant_div(y[e], d);
+                            if (vec_ok && n + 3 < g.N) {
+                                *reinterpret_cast<uint32_t*>(o) = requant4_i8(y[0], y[1], y[2], y[3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < g.N) o[e] = requant1_i8(y[e]);
                             }
                         } else {
                             uint16_t* o = static_cast<uint16_t*>(g.out) + idx;

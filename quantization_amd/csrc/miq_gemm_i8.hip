@@ -38,7 +38,28 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int kt_per_split;  // K-tiles each blockIdx.y slice sums (split-K: raw int32 slabs out); 0 = all of K
     unsigned* stamps;  // timing-only builds: per-wave cycle totals of the main loop's segments
+    int by_row;        // != 0: bias / alpha are indexed by the output ROW m (the transposed product: its rows are the channels)
+    float out_div;     // int8 outputs: clamp(rint(y / out_div)); 1 = the dequantised value itself
 };
+
+// One output element from its int32 sum: the epilogue of the kernels that finish one element per thread.
+template <int OUT>
+__device__ __forceinline__ void store_one(const GemmArgs& g, int m, int n, int sum) {
+    const size_t o = static_cast<size_t>(m) * g.ldc + n;
+    if constexpr (OUT == kOutI32) {
+        static_cast<int*>(g.out)[o] = sum;
+    } else {
+        const int pi = g.by_row ? m : n;
+        const float y = dequant1(sum, g.bias ? g.bias[pi] : 0.0f, g.alpha[pi], g.beta);
+        if constexpr (OUT == kOutF32) {
+            static_cast<float*>(g.out)[o] = y;
+        } else if constexpr (OUT == kOutI8) {
+            static_cast<int8_t*>(g.out)[o] = requant1_i8(requant_div(y, g.out_div));
+        } else {
+            static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y);
+        }
+    }
+}
 
 // Fills one LDS stage: rows [row0, row0 + ROWS) x K-tile kt of a [nrows, K] int8 matrix.
 // Each wave-instruction moves 8 rows x 128 B; the chunk a lane fetches is the one its LDS
@@ -169,12 +190,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
         const int n = ncol + j * 16;
         float al[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUT != kOutI32) {
+            if (!g.by_row) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < g.N) {
-                    al[e] = g.alpha[n + e];
-                    if (g.bias) bi[e] = g.bias[n + e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) {
+                        al[e] = g.alpha[n + e];
+                        if (g.bias) bi[e] = g.bias[n + e];
+                    }
+            }
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -192,6 +215,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
                         if (n + e < g.N) o[e] = a[e];
                 }
             } else {
+                if (g.by_row) {   // the parameters of output row m, for all of this lane's columns
+                    const float ar = g.alpha[m], br = g.bias ? g.bias[m] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        al[e] = ar;
+                        bi[e] = br;
+                    }
+                }
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = dequant1(a[e], bi[e], al[e], g.beta);
@@ -203,6 +234,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_i8_kernel(GemmArg
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (n + e < g.N) o[e] = y[e];
+                    }
+                } else if constexpr (OUT == kOutI8) {
+                    int8_t* o = static_cast<int8_t*>(g.out) + idx;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = requant_div(y[e], g.out_div);
+                    if (vec_ok && n + 3 < g.N) {
+                        *reinterpret_cast<uint32_t*>(o) = requant4_i8(y[0], y[1], y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) o[e] = requant1_i8(y[e]);
                     }
                 } else {
                     uint16_t* o = static_cast<uint16_t*>(g.out) + idx;
@@ -606,7 +648,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
 
-    store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0>(g, acc, m0, n0, wm, wn, lane);
+    store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0, 2, true>(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -835,7 +877,7 @@ __global__ __launch_bounds__(512) void gemm_i8_wide_kernel(GemmArgs g) {
     if (wm == 0) MIQ_BARRIER();   // every wave executes the same number of barriers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-record DMAs issued for the tiles past K
 
-    store_tile_256<OUT, true, true, 3>(g, acc, m0, n0, wm, wn, lane);
+    store_tile_256<OUT, true, true, 3, true>(g, acc, m0, n0, wm, wn, lane);
 }
 #endif   // MIQ_NO_DEV_SWITCHES
 
@@ -850,17 +892,7 @@ __global__ __launch_bounds__(256) void gemm_i8_any_kernel(GemmArgs g) {
         const int8_t* w = g.W + static_cast<int64_t>(n) * g.K;
         int sum = 0;
         for (int k = 0; k < g.K; ++k) sum += static_cast<int>(a[k]) * static_cast<int>(w[k]);
-        const size_t o = static_cast<size_t>(m) * g.ldc + n;
-        if constexpr (OUT == kOutI32) {
-            static_cast<int*>(g.out)[o] = sum;
-        } else {
-            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
-            if constexpr (OUT == kOutF32) {
-                static_cast<float*>(g.out)[o] = y;
-            } else {
-                static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y);
-            }
-        }
+        store_one<OUT>(g, m, n, sum);
     }
 }
 
@@ -871,18 +903,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const int* __restric
     for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
         int sum = 0;
         for (int s = 0; s < splits; ++s) sum += slabs[s * total + idx];
-        const int n = static_cast<int>(idx % g.N);
-        const size_t o = static_cast<size_t>(idx / g.N) * g.ldc + n;
-        if constexpr (OUT == kOutI32) {
-            static_cast<int*>(g.out)[o] = sum;
-        } else {
-            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
-            if constexpr (OUT == kOutF32) {
-                static_cast<float*>(g.out)[o] = y;
-            } else {
-                static_cast<uint16_t*>(g.out)[o] = f32_to_bf16_bits(y);
-            }
-        }
+        store_one<OUT>(g, static_cast<int>(idx / g.N), static_cast<int>(idx % g.N), sum);
     }
 }
 
@@ -986,17 +1007,7 @@ __global__ __launch_bounds__(512) void gemm_i8_skinny_kernel(GemmArgs g) {
         int sum = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) sum += red[w * MT * WN * 256 + src];
-        const size_t idx = static_cast<size_t>(m) * g.ldc + n;
-        if constexpr (OUT == kOutI32) {
-            static_cast<int*>(g.out)[idx] = sum;
-        } else {
-            const float y = dequant1(sum, g.bias ? g.bias[n] : 0.0f, g.alpha[n], g.beta);
-            if constexpr (OUT == kOutF32) {
-                static_cast<float*>(g.out)[idx] = y;
-            } else {
-                static_cast<uint16_t*>(g.out)[idx] = f32_to_bf16_bits(y);
-            }
-        }
+        store_one<OUT>(g, m, n, sum);
     }
 }
 
@@ -1358,39 +1369,62 @@ int scratch_for_current_device(void** out) {
     return MIQ_OK;
 }
 
-bool mfma_path_ok(const int8_t* A, const int8_t* W, int w_layout, int64_t N, int64_t K, const void* out) {
-    // 16-byte vector stores in the epilogue (four fp32 / int32, or eight bf16 when N % 8 == 0) need 16-byte
-    // aligned output rows whenever N % 4 == 0.  A [K,N] weight is re-laid into the 256-byte aligned workspace.
-    const bool out_vec_ok = (N % 4 != 0) || aligned(out, 16);
+bool mfma_path_ok(const int8_t* A, const int8_t* W, int w_layout, int64_t ldo, int64_t K, const void* out) {
+    // 16-byte vector stores in the epilogue (four fp32 / int32, or eight bf16 when ldo % 8 == 0; four int8 as a dword)
+    // need 16-byte aligned output rows whenever ldo % 4 == 0.  A [K,N] weight is re-laid into the 256-byte aligned
+    // workspace.
+    const bool out_vec_ok = (ldo % 4 != 0) || aligned(out, 16);
     return K > 0 && K % 16 == 0 && aligned(A, 16) && (w_layout == MIQ_W_KN || aligned(W, 16)) && out_vec_ok;
 }
 
+size_t out_esz(int out_dtype) { return out_dtype == MIQ_I8 ? 1 : out_dtype == MIQ_BF16 ? 2 : 4; }
+
+// Output placement and requantisation of one call (miq_gemm_i8_ex; the plain entry points use the defaults).
+struct OutSpec {
+    int layout;       // MIQ_OUT_MN: out[m * ldo + n]; MIQ_OUT_NM: out[n * ldo + m]
+    int64_t ldo;      // elements between two rows of `out`
+    float out_div;    // MIQ_I8: clamp(rint(y / out_div))
+};
+
 int validate(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K, const float* bias,
-             const float* alpha, const void* out, int out_dtype, const char* who) {
+             const float* alpha, const void* out, int out_dtype, const OutSpec& os, bool extended, const char* who) {
     MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "%s: negative size (M=%lld N=%lld K=%lld)", who, (long long)M,
                 (long long)N, (long long)K);
     MIQ_REQUIRE(w_layout == MIQ_W_NK || w_layout == MIQ_W_KN, MIQ_EINVAL, "%s: unknown w_layout %d", who, w_layout);
-    MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32, MIQ_EINVAL,
-                "%s: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", who, out_dtype);
+    if (extended) {
+        MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32 || out_dtype == MIQ_I8, MIQ_EINVAL,
+                    "%s: out_dtype must be MIQ_F32, MIQ_BF16, MIQ_I32 or MIQ_I8 (got %d)", who, out_dtype);
+        MIQ_REQUIRE(os.layout == MIQ_OUT_MN || os.layout == MIQ_OUT_NM, MIQ_EINVAL, "%s: unknown out_layout %d", who, os.layout);
+        MIQ_REQUIRE(os.ldo >= (os.layout == MIQ_OUT_MN ? N : M), MIQ_EINVAL,
+                    "%s: ldo (%lld) is smaller than a row of the output (%lld)", who, (long long)os.ldo,
+                    (long long)(os.layout == MIQ_OUT_MN ? N : M));
+        MIQ_REQUIRE(out_dtype != MIQ_I8 || (os.out_div > 0.0f && os.out_div < __builtin_inff()), MIQ_EINVAL,
+                    "%s: requant_scale must be positive and finite (got %g)", who, (double)os.out_div);
+    } else {
+        MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || out_dtype == MIQ_I32, MIQ_EINVAL,
+                    "%s: out_dtype must be MIQ_F32, MIQ_BF16 or MIQ_I32 (got %d)", who, out_dtype);
+    }
     if (M == 0 || N == 0) return MIQ_OK;
     MIQ_REQUIRE(out, MIQ_EINVAL, "%s: null output", who);
     MIQ_REQUIRE(K == 0 || (A && W), MIQ_EINVAL, "%s: null operand", who);
     MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "%s: alpha is required for a dequantised output", who);
-    MIQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && M * K < (1ll << 31) && N * K < (1ll << 31),
+    MIQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && M * K < (1ll << 31) && N * K < (1ll << 31) &&
+                    os.ldo < (1ll << 31),
                 MIQ_ERANGE, "%s: operands are indexed with 31-bit byte offsets (M*K and N*K < 2^31)", who);
-    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
-    MIQ_REQUIRE(aligned(out, esz) && aligned(alpha, 4) && aligned(bias, 4), MIQ_EALIGN,
+    MIQ_REQUIRE(aligned(out, out_esz(out_dtype)) && aligned(alpha, 4) && aligned(bias, 4), MIQ_EALIGN,
                 "%s: out/alpha/bias not aligned to their element size", who);
     return MIQ_OK;
 }
 
 // Everything after validation and the workspace check: the optional weight re-layout and the launches of the
-// schedule.  `workspace` holds transposed_bytes() + sched.slab_bytes bytes.
+// schedule.  `workspace` holds transposed_bytes() + sched.slab_bytes bytes.  (M, N) are the caller's; a transposed
+// output swaps the operands' roles: the kernels then see the weight as their row operand (Mk = N rows), the activation
+// as their column operand (Nk = M), write out[n * ldo + m] as an ordinary row-major result and take bias / alpha by row.
 int run_schedule(const Schedule& sched, const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
-                 const float* bias, const float* alpha, float beta, void* out, int out_dtype, bool mfma_ok,
+                 const float* bias, const float* alpha, float beta, void* out, int out_dtype, const OutSpec& os, bool mfma_ok,
                  void* workspace, void* stream) {
     hipStream_t st = as_stream(stream);
-    const size_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
+    const size_t esz = out_esz(out_dtype);
     int* slabs = nullptr;
     if (K > 0) {
         if (w_layout == MIQ_W_KN) {
@@ -1400,12 +1434,15 @@ int run_schedule(const Schedule& sched, const int8_t* A, const int8_t* W, int w_
         }
         if (sched.slab_bytes) slabs = reinterpret_cast<int*>(static_cast<char*>(workspace) + transposed_bytes(w_layout, N, K));
     }
-    GemmArgs g{A, W, bias, alpha, out, beta, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K),
-               static_cast<int>(N), 0, 0, 0, nullptr};
+    const bool tr = os.layout == MIQ_OUT_NM;
+    const int64_t Mk = tr ? N : M, Nk = tr ? M : N;
+    GemmArgs g{tr ? W : A, tr ? A : W, bias, alpha, out, beta, static_cast<int>(Mk), static_cast<int>(Nk), static_cast<int>(K),
+               static_cast<int>(os.ldo), 0, 0, 0, nullptr, tr ? 1 : 0, os.out_div};
     if (!mfma_ok) {
         switch (out_dtype) {
             case MIQ_F32: return launch_any<kOutF32>(g, st);
             case MIQ_BF16: return launch_any<kOutBF16>(g, st);
+            case MIQ_I8: return launch_any<kOutI8>(g, st);
             default: return launch_any<kOutI32>(g, st);
         }
     }
@@ -1413,36 +1450,68 @@ int run_schedule(const Schedule& sched, const int8_t* A, const int8_t* W, int w_
         switch (out_dtype) {
             case MIQ_F32: return launch<kOutF32>(part, plan, part_slabs, st);
             case MIQ_BF16: return launch<kOutBF16>(part, plan, part_slabs, st);
+            case MIQ_I8: return launch<kOutI8>(part, plan, part_slabs, st);
             default: return launch<kOutI32>(part, plan, part_slabs, st);
         }
     };
-    if (sched.wide_n) {
+    if (sched.wide_n) {   // (developer library only; plain row-major outputs)
         GemmArgs wide = g;
         wide.N = static_cast<int>(sched.wide_n);
         int rc;
         switch (out_dtype) {
             case MIQ_F32: rc = launch_wide<kOutF32>(wide, st); break;
             case MIQ_BF16: rc = launch_wide<kOutBF16>(wide, st); break;
+            case MIQ_I8: rc = launch_wide<kOutI8>(wide, st); break;
             default: rc = launch_wide<kOutI32>(wide, st); break;
         }
-        if (rc != MIQ_OK || sched.wide_n == N) return rc;
+        if (rc != MIQ_OK || sched.wide_n == Nk) return rc;
         // the remaining channels: a column block of the same output
-        g.W = W + sched.wide_n * K;
-        if (bias) g.bias = bias + sched.wide_n;
-        if (alpha) g.alpha = alpha + sched.wide_n;
+        g.W = g.W + sched.wide_n * K;
+        if (bias && !tr) g.bias = bias + sched.wide_n;
+        if (alpha && !tr) g.alpha = alpha + sched.wide_n;
         g.out = static_cast<char*>(out) + static_cast<size_t>(sched.wide_n) * esz;
-        g.N = static_cast<int>(N - sched.wide_n);
+        g.N = static_cast<int>(Nk - sched.wide_n);
     }
-    if (sched.head_m < M) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
+    if (sched.head_m < Mk) {   // whole rounds of 256 x 256 tiles, then the remaining rows as their own problem
         GemmArgs head = g, tail = g;
         head.M = static_cast<int>(sched.head_m);
         if (int rc = run(head, sched.head, nullptr)) return rc;
-        tail.A = A + sched.head_m * K;
-        tail.out = static_cast<char*>(g.out) + static_cast<size_t>(sched.head_m) * N * esz;
-        tail.M = static_cast<int>(M - sched.head_m);
+        tail.A = g.A + sched.head_m * K;
+        tail.out = static_cast<char*>(g.out) + static_cast<size_t>(sched.head_m) * os.ldo * esz;
+        tail.M = static_cast<int>(Mk - sched.head_m);
+        if (tr) {   // row parameters move with the rows
+            if (bias) tail.bias = bias + sched.head_m;
+            if (alpha) tail.alpha = alpha + sched.head_m;
+        }
         return run(tail, sched.tail, slabs);
     }
     return run(g, sched.head, slabs);
+}
+
+// The common body of the entry points.  scratch_mode: the workspace is the library's own buffer (miq_gemm_i8_noalloc).
+int gemm_i8_call(const char* who, bool extended, bool scratch_mode, const int8_t* A, const int8_t* W, int w_layout, int64_t M,
+                 int64_t N, int64_t K, const float* bias, const float* alpha, float beta, void* out, int out_dtype, OutSpec os,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = validate(A, W, w_layout, M, N, K, bias, alpha, out, out_dtype, os, extended, who)) return rc;
+    if (M == 0 || N == 0) return MIQ_OK;
+    const bool tr = os.layout == MIQ_OUT_NM;
+    const bool mfma_ok = mfma_path_ok(A, W, w_layout, os.ldo, K, out);
+    const Schedule sched = make_schedule(tr ? N : M, tr ? M : N, K, mfma_ok);
+    const size_t need = K > 0 ? transposed_bytes(w_layout, N, K) + sched.slab_bytes : 0;
+    if (scratch_mode) {
+        MIQ_REQUIRE(need <= kScratchBytes, MIQ_EWORKSPACE,
+                    "%s: this call needs %zu bytes of scratch, the built-in buffer holds %zu: use miq_gemm_i8 "
+                    "with a caller workspace", who, need, kScratchBytes);
+        workspace = nullptr;
+        if (need) {
+            if (int rc = scratch_for_current_device(&workspace)) return rc;
+        }
+    } else if (need) {
+        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
+                    "%s: this call needs %zu bytes of workspace (got %zu): see %s_workspace", who, need, workspace_bytes, who);
+        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "%s: workspace must be 256-byte aligned", who);
+    }
+    return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, os, mfma_ok, workspace, stream);
 }
 
 }  // namespace
@@ -1457,18 +1526,21 @@ extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int6
 extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
                            const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (int rc = validate(A, W, w_layout, M, N, K, bias, alpha, out, out_dtype, "miq_gemm_i8")) return rc;
-    if (M == 0 || N == 0) return MIQ_OK;
-    const bool mfma_ok = mfma_path_ok(A, W, w_layout, N, K, out);
-    const Schedule sched = make_schedule(M, N, K, mfma_ok);
-    const size_t need = K > 0 ? transposed_bytes(w_layout, N, K) + sched.slab_bytes : 0;
-    if (need) {
-        MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE,
-                    "miq_gemm_i8: this call needs %zu bytes of workspace (got %zu): see miq_gemm_i8_workspace", need,
-                    workspace_bytes);
-        MIQ_REQUIRE(miq::aligned(workspace, 256), MIQ_EALIGN, "miq_gemm_i8: workspace must be 256-byte aligned");
-    }
-    return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, mfma_ok, workspace, stream);
+    return gemm_i8_call("miq_gemm_i8", false, false, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype,
+                        OutSpec{MIQ_OUT_MN, N, 1.0f}, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t miq_gemm_i8_ex_workspace(int w_layout, int out_layout, int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const bool tr = out_layout == MIQ_OUT_NM;
+    return transposed_bytes(w_layout, N, K) + make_schedule(tr ? N : M, tr ? M : N, K, K % 16 == 0).slab_bytes;
+}
+
+extern "C" int miq_gemm_i8_ex(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
+                              const float* bias, const float* alpha, float beta, void* out, int out_dtype, int out_layout,
+                              int64_t ldo, float requant_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_i8_call("miq_gemm_i8_ex", true, false, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype,
+                        OutSpec{out_layout, ldo, requant_scale}, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t miq_gemm_i8_noalloc_max_workspace(void) { return kScratchBytes; }
@@ -1476,17 +1548,6 @@ extern "C" size_t miq_gemm_i8_noalloc_max_workspace(void) { return kScratchBytes
 extern "C" int miq_gemm_i8_noalloc(const int8_t* A, const int8_t* W, int w_layout, int64_t M, int64_t N, int64_t K,
                                    const float* bias, const float* alpha, float beta, void* out, int out_dtype,
                                    void* stream) {
-    if (int rc = validate(A, W, w_layout, M, N, K, bias, alpha, out, out_dtype, "miq_gemm_i8_noalloc")) return rc;
-    if (M == 0 || N == 0) return MIQ_OK;
-    const bool mfma_ok = mfma_path_ok(A, W, w_layout, N, K, out);
-    const Schedule sched = make_schedule(M, N, K, mfma_ok);
-    const size_t need = K > 0 ? transposed_bytes(w_layout, N, K) + sched.slab_bytes : 0;
-    MIQ_REQUIRE(need <= kScratchBytes, MIQ_EWORKSPACE,
-                "miq_gemm_i8_noalloc: this call needs %zu bytes of scratch, the built-in buffer holds %zu: use miq_gemm_i8 "
-                "with a caller workspace", need, kScratchBytes);
-    void* ws = nullptr;
-    if (need) {
-        if (int rc = scratch_for_current_device(&ws)) return rc;
-    }
-    return run_schedule(sched, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype, mfma_ok, ws, stream);
+    return gemm_i8_call("miq_gemm_i8_noalloc", false, true, A, W, w_layout, M, N, K, bias, alpha, beta, out, out_dtype,
+                        OutSpec{MIQ_OUT_MN, N, 1.0f}, nullptr, 0, stream);
 }

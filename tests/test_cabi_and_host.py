@@ -101,7 +101,7 @@ def test_product_library_has_no_developer_kernels():
     from quantization_amd import _native
     syms = subprocess.run(["nm", "-C", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
     stubs = sorted(set(re.findall(r"__device_stub__gemm_i8_256_kernel<(\d+), (\d+), (\d+)>", syms)))
-    assert stubs == [("0", "5", "0"), ("2", "5", "0"), ("3", "5", "0")], stubs
+    assert stubs == [("0", "5", "0"), ("2", "5", "0"), ("3", "5", "0"), ("4", "5", "0")], stubs   # fp32, bf16, int32, int8 out
     assert "gemm_i8_wide_kernel" not in syms
     dyn = subprocess.run(["nm", "-D", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in dyn, "the product library must not read developer switches"

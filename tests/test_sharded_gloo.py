@@ -69,9 +69,26 @@ def _worker(rank, world, port, n, K, M, tmp):
         yb = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, gather_dtype=torch.bfloat16)(x)
         yq = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, gather_dtype=torch.int8,
                                             act_scale=ACT_SCALE)(x)
+        # the transposed placement: every rank gathers out^T; to_dense() is a view of the gathered buffer when N divides
+        # by the world size
+        lt = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, transposed=True)
+        yt = lt(x)
+        assert tuple(yt.shape) == (M, n)
+        if n % world == 0:
+            assert yt.t().is_contiguous()                    # [N, M] storage: no re-arranging pass happened
+        assert torch.equal(torch.cat(lt(x, dense=False), dim=1), yt)
+        ytq = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, transposed=True,
+                                             gather_dtype=torch.int8, act_scale=ACT_SCALE)(x)
+        # results are the caller's: a second forward on other activations leaves the first result alone
+        x2 = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32).to(torch.int8)
+        keep = y.clone()
+        blocks_keep = [b.clone() for b in blocks]
+        layer(x2)
+        layer(x2, dense=False)
+        assert torch.equal(y, keep) and all(torch.equal(a, b) for a, b in zip(blocks, blocks_keep))
         if rank == world - 1:                                # the last rank: the narrowest shard of a ragged split
             np.savez(tmp, y=y.numpy(), y0=ys[0].numpy(), y1=ys[1].numpy(), w=w.numpy(), w2=w2.numpy(),
-                     bias=bias.numpy(), x=x.numpy(), yb=yb.float().numpy(), yq=yq.numpy())
+                     bias=bias.numpy(), x=x.numpy(), yb=yb.float().numpy(), yq=yq.numpy(), yt=yt.numpy(), ytq=ytq.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -91,6 +108,33 @@ def test_column_sharded_linear_equals_unsharded(tmp_path, world, n, K, M):
     # what the narrower gathers deliver: the fp32 result rounded once to bf16 / requantised with the static scale
     np.testing.assert_array_equal(z["yb"], O.round_f32_to_bf16(ref))
     np.testing.assert_array_equal(z["yq"], np.clip(np.rint(ref / np.float32(ACT_SCALE)), -128, 127).astype(np.int8))
+    np.testing.assert_array_equal(z["yt"], ref)
+    np.testing.assert_array_equal(z["ytq"], z["yq"])
+
+
+def test_single_rank_results_are_owned_by_the_caller():
+    """One rank (no process group): y1 = layer(x1); y2 = layer(x2) must leave y1 alone, for the dense result, the block
+    list and the transposed placement alike (a cached gather buffer handed out as the result would be overwritten)."""
+    from quantization_amd.sharded import ColumnShardedLinear
+    g = torch.Generator().manual_seed(3)
+    w, bias = torch.randn(24, 16, generator=g), torch.randn(24, generator=g)
+    x1 = torch.randint(-128, 128, (5, 16), generator=g, dtype=torch.int32).to(torch.int8)
+    x2 = torch.randint(-128, 128, (5, 16), generator=g, dtype=torch.int32).to(torch.int8)
+    q, s, _ = O.quantize_channel_sym_int8(w.numpy())
+    ref1 = O.wo_linear_forward(x1.numpy(), q, s, bias.numpy())
+    for transposed in (False, True):
+        layer = ColumnShardedLinear.from_float(w, bias, gemm=_cpu_gemm, quantize=_cpu_quantize, transposed=transposed)
+        y1 = layer(x1)
+        b1 = layer(x1, dense=False)
+        y2 = layer(x2)
+        layer(x2, dense=False)
+        np.testing.assert_array_equal(y1.numpy(), ref1)
+        np.testing.assert_array_equal(b1[0].numpy(), ref1)
+        assert not torch.equal(y1, y2)
+        # the cached form says so in its contract: same slot, same rows -> the buffer is reused
+        a = layer.gather_async(x1, slot=0).to_dense()
+        layer.gather_async(x2, slot=0)
+        np.testing.assert_array_equal(a.numpy(), y2.numpy())
 
 
 def test_from_float_checks_the_rows_it_is_given():
