@@ -337,6 +337,27 @@ int miq_tensor_minmax(const void* x, int x_dtype, int64_t n, float* min_max, voi
 int miq_dynamic_epilogue_i8(const float* min_max, const float* w_scale, const float* bias, const float* w_rowsum,
                             int64_t n, float* scale_zp, float* alpha, float* corr, void* stream);
 
+/* The two calls above and the statistics before them as ONE launch, and the quantization as a second: what a layer with a
+ * dynamic per-tensor activation quantizer runs per forward (the step the reference configures, Quantizer.py:38-44, and
+ * leaves commented out, Quantizer.py:69-70).
+ *   miq_dynamic_quant_params_i8: min / max over the n elements of x; scale_zp[0] = scale, scale_zp[1] = zero point as a
+ *     float, scale_zp[2] = the zero point's int32 bits (formulas of miq_dynamic_epilogue_i8); and, when channels > 0,
+ *     alpha[c] / corr[c] of miq_dynamic_epilogue_i8.  workspace: miq_dynamic_quant_workspace(n) bytes.  counter: one
+ *     4-byte device word that is ZERO on entry and is left zero (the workgroups count themselves in; the last one
+ *     finishes the reduction): allocate and clear it once; calls that share a counter must not overlap in time.
+ *   miq_quantize_tensor_i8: q = int8(clamp(rint(x / scale + zero_point), -128, 127)) (Qop.py:157; IEEE division, fp16 /
+ *     bf16 inputs round to their type after the division and after the addition, as tensor arithmetic does) for x
+ *     [planes, H, W] with scale = scale_zp[0], zero_point = scale_zp[1] read on the device; q is
+ *     [planes, H + pad_top + pad_bottom, W + pad_left + pad_right] whose frame is filled with the zero point: a padded
+ *     position of a convolution holds the real value 0, whose quantized form is the zero point. */
+size_t miq_dynamic_quant_workspace(int64_t n);
+int miq_dynamic_quant_params_i8(const void* x, int x_dtype, int64_t n, const float* w_scale, const float* bias,
+                                const float* w_rowsum, int64_t channels, float* scale_zp, float* alpha, float* corr,
+                                void* workspace, size_t workspace_bytes, unsigned* counter, void* stream);
+int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes, int64_t H, int64_t W, int64_t pad_top,
+                           int64_t pad_bottom, int64_t pad_left, int64_t pad_right, const float* scale_zp, int8_t* q,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

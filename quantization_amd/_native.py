@@ -66,6 +66,9 @@ SYMBOLS = {
     "miq_tensor_minmax_workspace": (_size, [_i64]),
     "miq_tensor_minmax": (_int, [_p, _int, _i64, _p, _p, _size, _p]),
     "miq_dynamic_epilogue_i8": (_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "miq_dynamic_quant_workspace": (_size, [_i64]),
+    "miq_dynamic_quant_params_i8": (_int, [_p, _int, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _size, _p, _p]),
+    "miq_quantize_tensor_i8": (_int, [_p, _int] + [_i64] * 7 + [_p, _p, _p]),
 }
 
 _lib = None
@@ -271,6 +274,67 @@ def dynamic_epilogue_i8(min_max, w_scale, bias, w_rowsum):
         _check(lib().miq_dynamic_epilogue_i8(_ptr(min_max), _ptr(w_scale), _ptr(bias), _ptr(w_rowsum), n, _ptr(scale_zp),
                                              _ptr(alpha), _ptr(corr), _stream()))
     return scale_zp, alpha, corr
+
+
+_counters = {}   # (device index, stream) -> a zeroed int32 word for miq_dynamic_quant_params_i8
+
+
+def _counter(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    c = _counters.get(key)
+    if c is None:
+        c = _counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return c
+
+
+def dynamic_quant_params(x, w_scale=None, bias=None, w_rowsum=None):
+    """One launch: min / max of x, the per-tensor affine int8 parameters and (with w_scale / w_rowsum given) the epilogue
+    vectors of a weight-only layer run on the quantized activation.  Returns (scale_zp [3] fp32: scale, zero point, the
+    zero point's int32 bits; alpha [N] or None; corr [N] or None).  No host synchronisation."""
+    require_device(x, "tensor")
+    if x.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"tensor must be float32, float16 or bfloat16 (got {x.dtype})")
+    if x.numel() == 0:
+        raise RuntimeError("the tensor is empty")
+    dev = x.device
+    n = 0
+    if w_scale is not None:
+        n = w_scale.numel()
+        w_scale = _f32_vec(w_scale, n, "w_scale", dev)
+        w_rowsum = _f32_vec(w_rowsum, n, "w_rowsum", dev)
+        bias = _f32_vec(bias, n, "bias", dev)
+    out = torch.empty(4 + 2 * n, dtype=torch.float32, device=dev)
+    scale_zp, alpha, corr = out[:3], (out[4:4 + n] if n else None), (out[4 + n:] if n else None)
+    L = lib()
+    need = L.miq_dynamic_quant_workspace(x.numel())
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _check(L.miq_dynamic_quant_params_i8(_ptr(x), _FLOAT_CODES[x.dtype], x.numel(), _ptr(w_scale), _ptr(bias), _ptr(w_rowsum),
+                                             n, _ptr(scale_zp), _ptr(alpha), _ptr(corr), _ptr(ws), ws.numel(), _ptr(_counter(dev)),
+                                             _stream()))
+    return scale_zp, alpha, corr
+
+
+def quantize_tensor_i8(x, scale_zp, pad=(0, 0, 0, 0)):
+    """q = int8(clamp(rint(x / scale_zp[0] + scale_zp[1]))) with the parameters read on the device.  pad = (top, bottom, left,
+    right): x is then [..., H, W] and q gets a frame of that width filled with the zero point."""
+    require_device(x, "tensor")
+    if x.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"tensor must be float32, float16 or bfloat16 (got {x.dtype})")
+    pt, pb, pl, pr = (int(v) for v in pad)
+    if pt or pb or pl or pr:
+        if x.dim() < 2:
+            raise RuntimeError("a framed tensor needs at least two dimensions")
+        H, W = x.shape[-2], x.shape[-1]
+        planes = x.numel() // max(H * W, 1)
+        q = torch.empty((*x.shape[:-2], H + pt + pb, W + pl + pr), dtype=torch.int8, device=x.device)
+    else:
+        planes, H, W = 1, 1, x.numel()
+        q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    with _on(x.device):
+        _check(lib().miq_quantize_tensor_i8(_ptr(x), _FLOAT_CODES[x.dtype], planes, H, W, pt, pb, pl, pr, _ptr(scale_zp), _ptr(q),
+                                            _stream()))
+    return q
 
 
 def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):

@@ -34,25 +34,18 @@ EPS = 2.0 ** -23   # torch.finfo(torch.float32).eps, the reference's floor for a
 
 @torch.no_grad()
 def tensor_params_i8(x):
-    """(scale [1] fp32, zero_point [1] int32) of x for the int8 range, on x's device."""
-    mm = _native.tensor_minmax(x.contiguous())
-    zero = torch.zeros((), dtype=torch.float32, device=x.device)
-    lo, hi = torch.minimum(mm[0], zero), torch.maximum(mm[1], zero)
-    # tensor / tensor: a division by a Python scalar becomes a multiplication by its reciprocal on the GPU
-    scale = (hi - lo) / torch.full((), float(Q_MAX - Q_MIN), dtype=torch.float32, device=x.device)
-    scale = torch.maximum(scale, torch.full((), EPS, dtype=torch.float32, device=x.device))
-    zp = (Q_MIN - torch.round(lo / scale)).to(torch.int32).clamp(Q_MIN, Q_MAX)
-    return scale.reshape(1), zp.reshape(1)
+    """(scale [1] fp32, zero_point [1] int32) of x for the int8 range, on x's device: one launch, no host synchronisation."""
+    scale_zp, _, _ = _native.dynamic_quant_params(x.contiguous())
+    return scale_zp[0:1], scale_zp[2:3].view(torch.int32)
 
 
 @torch.no_grad()
 def quantize_tensor_i8(x):
-    """x (float) -> (q int8 of x's shape, scale [1], zero_point [1])."""
+    """x (float) -> (q int8 of x's shape, scale [1], zero_point [1]).  Two launches: statistics + parameters, quantize."""
     x = x.contiguous()
-    scale, zp = tensor_params_i8(x)
-    rows = x.shape[0] if x.dim() > 1 else 1
-    q = _native.quantize_rows_given_i8(x.reshape(rows, -1), scale, zp.to(torch.float32))
-    return q.view(x.shape), scale, zp
+    scale_zp, _, _ = _native.dynamic_quant_params(x)
+    q = _native.quantize_tensor_i8(x, scale_zp)
+    return q, scale_zp[0:1], scale_zp[2:3].view(torch.int32)
 
 
 @torch.no_grad()
@@ -65,42 +58,41 @@ def weight_rowsum(wq):
 def linear_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, out_dtype=torch.float32):
     """Weight-only quantized Linear on a float activation, through the int8 GEMM: x is quantized per
     tensor on the fly and the zero-point correction, both scales and the bias ride the fused epilogue.
-    Five launches, nothing on the host: min/max (two), parameters + epilogue vectors, quantize, GEMM."""
+    Three launches, nothing on the host: statistics + parameters + epilogue vectors, quantize, GEMM."""
     _native.require_device(x, "input")
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     if w_rowsum is None:
         w_rowsum = weight_rowsum(wq)
-    scale_zp, alpha, corr = _native.dynamic_epilogue_i8(_native.tensor_minmax(x2), w_scale, bias, w_rowsum)
-    xq = _native.quantize_rows_given_i8(x2, scale_zp[0:1], scale_zp[1:2])
+    scale_zp, alpha, corr = _native.dynamic_quant_params(x2, w_scale, bias, w_rowsum)
+    xq = _native.quantize_tensor_i8(x2, scale_zp)
     y = _native.gemm_i8(xq, wq, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
     return y.view(*lead, y.shape[-1])
 
 
 @torch.no_grad()
 def conv2d_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, stride=1, padding=0, out_dtype=torch.float32,
-                        dilation=1, groups=1):
-    """Weight-only quantized Conv2d on a float activation x [B, Cin, H, W], through the int8 convolution: x is
-    quantized per tensor on the fly into a frame filled with its zero point, and the zero-point correction, both
-    scales and the bias ride the fused epilogue.  Nothing on the host.  stride / padding / dilation / groups as
-    nn.Conv2d takes them; anything but one stride, one numeric padding, dilation 1 and groups 1 runs on the direct
-    convolution kernel."""
+                        dilation=1, groups=1, packed=None):
+    """Weight-only quantized Conv2d on a float activation x [B, Cin, H, W] (or one image [Cin, H, W]), through the int8
+    convolution: x is quantized per tensor on the fly straight into a frame filled with its zero point, and the zero-point
+    correction, both scales and the bias ride the fused epilogue.  Nothing on the host.  stride / padding / dilation /
+    groups as nn.Conv2d takes them; anything but one stride, one numeric padding, dilation 1 and groups 1 runs on the
+    general convolution entry point.  packed: conv2d_i8_pack_weight(wq), made once per layer."""
     _native.require_device(x, "input")
+    if x.dim() == 3:   # F.conv2d also takes one image
+        return conv2d_dynamic_w8a8(x.unsqueeze(0), wq, w_scale, bias, w_rowsum, stride, padding, out_dtype, dilation, groups,
+                                   packed).squeeze(0)
+    if x.dim() != 4:
+        raise RuntimeError(f"input must be [B, C, H, W] or [C, H, W] (got {tuple(x.shape)})")
     x = x.contiguous()
-    B, C, H, W = x.shape
     if w_rowsum is None:
         w_rowsum = weight_rowsum(wq)
-    pt, pb, pl, pr = _native.conv_padding(padding, wq.shape[2], wq.shape[3], stride, dilation)
-    scale_zp, alpha, corr = _native.dynamic_epilogue_i8(_native.tensor_minmax(x), w_scale.reshape(-1), bias, w_rowsum)
-    xq = _native.quantize_rows_given_i8(x.view(B * C, H * W), scale_zp[0:1], scale_zp[1:2]).view(B, C, H, W)
-    if pt or pb or pl or pr:
-        framed = torch.empty((B, C, H + pt + pb, W + pl + pr), dtype=torch.int8, device=x.device)
-        framed.copy_(scale_zp[1].to(torch.int8))          # the zero point is integral and within [-128, 127]
-        framed[:, :, pt:pt + H, pl:pl + W].copy_(xq)
-        xq = framed
+    pad = _native.conv_padding(padding, wq.shape[2], wq.shape[3], stride, dilation)
+    scale_zp, alpha, corr = _native.dynamic_quant_params(x, w_scale.reshape(-1), bias, w_rowsum)
+    xq = _native.quantize_tensor_i8(x, scale_zp, pad)
     sh, sw = _native._pair(stride)
     dh, dw = _native._pair(dilation)
     if sh == sw and dh == dw == 1 and groups == 1:
-        return _native.conv2d_i8(xq, wq, sh, 0, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
+        return _native.conv2d_i8(xq, wq, sh, 0, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype, packed=packed)
     return _native.conv2d_general(xq, wq, (sh, sw), 0, (dh, dw), groups, bias=corr, alpha=alpha, beta=0.0,
                                   out_dtype=out_dtype)

@@ -151,6 +151,175 @@ __global__ __launch_bounds__(kBlock) void dynamic_epilogue_kernel(const float* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The dynamic activation quantizer in two launches.
+//
+// dynamic_params_kernel: every workgroup leaves the (min, max) of its share of x in `parts` and takes a ticket from
+// `counter` (a device-scope atomic behind a device-scope fence, so that its pair is visible to whoever reads the
+// counter after it).  The workgroup that draws the last ticket folds the pairs, derives the per-tensor affine
+// parameters (Qop.calculate_params, quant/Weight_Only/Qop.py:40-41, 62-65) and, for a weight-only layer, the epilogue
+// vectors of its int8 product, and sets the counter back to zero: one launch where the statistics, the parameters and
+// the vectors took three.  quantize_tensor_kernel then applies Qop.py:157 with those parameters, optionally into the
+// interior of a frame filled with the zero point (a convolution's padding made explicit).
+// ---------------------------------------------------------------------------------------
+template <int DT, bool VECTOR>
+__global__ __launch_bounds__(kBlock) void dynamic_params_kernel(const void* __restrict__ x, int64_t n, float* __restrict__ parts,
+                                                                unsigned* __restrict__ counter, const float* __restrict__ w_scale,
+                                                                const float* __restrict__ bias, const float* __restrict__ w_rowsum,
+                                                                int64_t nch, float* __restrict__ scale_zp,
+                                                                float* __restrict__ alpha, float* __restrict__ corr) {
+    using E = Elems<DT>;
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(gridDim.x) * kBlock;
+    if constexpr (VECTOR) {
+        const int64_t nvec = n / E::kPerVec;
+        const uint4* src = static_cast<const uint4*>(x);
+        for (int64_t i = tid; i < nvec; i += nthreads) {
+            float f[E::kPerVec];
+            E::unpack(src[i], f);
+#pragma unroll
+            for (int e = 0; e < E::kPerVec; ++e) {
+                lo = fminf(lo, f[e]);
+                hi = fmaxf(hi, f[e]);
+            }
+        }
+        for (int64_t i = nvec * E::kPerVec + tid; i < n; i += nthreads) {   // tail
+            const float v = E::load1(x, i);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const float v = E::load1(x, i);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    block_minmax(lo, hi);
+    __shared__ unsigned ticket;
+    if (threadIdx.x == 0) {
+        parts[2 * blockIdx.x] = lo;
+        parts[2 * blockIdx.x + 1] = hi;
+        __threadfence();                        // the pair is visible device-wide before the ticket is taken
+        ticket = atomicAdd(counter, 1u);
+    }
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;        // (uniform over the workgroup)
+    __threadfence();                            // ... and every earlier workgroup's pair is visible to this one
+    lo = INFINITY;
+    hi = -INFINITY;
+    for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += kBlock) {
+        lo = fminf(lo, __builtin_nontemporal_load(parts + 2 * i));
+        hi = fmaxf(hi, __builtin_nontemporal_load(parts + 2 * i + 1));
+    }
+    __syncthreads();                            // block_minmax's LDS words are read by every thread above
+    block_minmax(lo, hi);
+    lo = fminf(lo, 0.0f);
+    hi = fmaxf(hi, 0.0f);
+    const float scale = fmaxf(__fsub_rn(hi, lo) / 255.0f, 1.1920928955078125e-07f);
+    float zp = __fsub_rn(-128.0f, rintf(lo / scale));
+    zp = fminf(fmaxf(truncf(zp), -128.0f), 127.0f);
+    if (threadIdx.x == 0) {
+        scale_zp[0] = scale;
+        scale_zp[1] = zp;
+        scale_zp[2] = __int_as_float(static_cast<int>(zp));   // the zero point as int32 bits (Qop keeps an integer tensor)
+        *counter = 0u;                                        // ready for the next call
+    }
+    for (int64_t i = threadIdx.x; i < nch; i += kBlock) {
+        alpha[i] = __fmul_rn(w_scale[i], scale);
+        const float c = __fmul_rn(-zp, w_rowsum[i]);
+        corr[i] = bias ? __fadd_rn(c, bias[i] / scale) : c;
+    }
+}
+
+// The storage-type rounding the reference's tensor arithmetic applies between operations (a bf16 / fp16 tensor divided
+// by a scalar tensor is rounded to bf16 / fp16 before the next operation).
+template <int DT>
+__device__ __forceinline__ float to_storage(float v) {
+    if constexpr (DT == MIQ_F16) return __half2float(__float2half_rn(v));
+    if constexpr (DT == MIQ_BF16) return __bfloat162float(__float2bfloat16(v));
+    return v;
+}
+
+template <int DT>
+__device__ __forceinline__ float quant1(float v, float s, float z) {
+    v = to_storage<DT>(v / s);
+    v = to_storage<DT>(__fadd_rn(v, z));
+    return fminf(fmaxf(rintf(v), -128.0f), 127.0f);
+}
+
+__device__ __forceinline__ uint32_t pack4_i8(float a, float b, float c, float d) {
+    return (static_cast<uint32_t>(static_cast<int>(a)) & 0xffu) | ((static_cast<uint32_t>(static_cast<int>(b)) & 0xffu) << 8) |
+           ((static_cast<uint32_t>(static_cast<int>(c)) & 0xffu) << 16) | (static_cast<uint32_t>(static_cast<int>(d)) << 24);
+}
+
+// q = int8(clamp(rint(x / scale + zp))), parameters read from the device (scale_zp[0], scale_zp[1]): one 16-byte load
+// and one 4- or 8-byte store per thread and step.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void quantize_tensor_kernel(const void* __restrict__ x, int64_t n,
+                                                                 const float* __restrict__ scale_zp, int8_t* __restrict__ q,
+                                                                 int vector) {
+    using E = Elems<DT>;
+    const float s = scale_zp[0], z = scale_zp[1];
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(gridDim.x) * kBlock;
+    int64_t done = 0;
+    if (vector) {
+        const int64_t nvec = n / E::kPerVec;
+        const uint4* src = static_cast<const uint4*>(x);
+        for (int64_t i = tid; i < nvec; i += nthreads) {
+            float f[E::kPerVec];
+            E::unpack(src[i], f);
+#pragma unroll
+            for (int e = 0; e < E::kPerVec; ++e) f[e] = quant1<DT>(f[e], s, z);
+            if constexpr (E::kPerVec == 4) {
+                reinterpret_cast<uint32_t*>(q)[i] = pack4_i8(f[0], f[1], f[2], f[3]);
+            } else {
+                reinterpret_cast<uint2*>(q)[i] = uint2{pack4_i8(f[0], f[1], f[2], f[3]), pack4_i8(f[4], f[5], f[6], f[7])};
+            }
+        }
+        done = nvec * E::kPerVec;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) q[i] = static_cast<int8_t>(static_cast<int>(quant1<DT>(E::load1(x, i), s, z)));
+}
+
+// The same into a frame: x is [planes, H, W], q is [planes, H + pt + pb, W + pl + pr]; the interior holds the quantized
+// image, the frame the zero point (the quantized form of the real value 0 a convolution pads with).  One thread per
+// four consecutive bytes of an output row.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void quantize_framed_kernel(const void* __restrict__ x, uint32_t rows_out, int H, int W,
+                                                                 int pt, int pl, int Hf, int Wf, const float* __restrict__ scale_zp,
+                                                                 int8_t* __restrict__ q) {
+    using E = Elems<DT>;
+    const float s = scale_zp[0], z = scale_zp[1];
+    const uint32_t segs = (static_cast<uint32_t>(Wf) + 3u) >> 2;
+    const uint64_t total = static_cast<uint64_t>(rows_out) * segs;
+    for (uint64_t idx = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; idx < total;
+         idx += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const uint32_t row = static_cast<uint32_t>(idx / segs), seg = static_cast<uint32_t>(idx - static_cast<uint64_t>(row) * segs);
+        const uint32_t plane = row / static_cast<uint32_t>(Hf), hf = row - plane * static_cast<uint32_t>(Hf);
+        const int h = static_cast<int>(hf) - pt;
+        const bool row_in = h >= 0 && h < H;
+        const int64_t src_row = (static_cast<int64_t>(plane) * H + h) * W;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = static_cast<int>(seg * 4 + k) - pl;
+            v[k] = (row_in && w >= 0 && w < W) ? quant1<DT>(E::load1(x, src_row + w), s, z) : z;
+        }
+        const uint64_t o = static_cast<uint64_t>(row) * Wf + seg * 4;
+        if (seg * 4 + 3 < static_cast<uint32_t>(Wf) && (o & 3) == 0) {
+            *reinterpret_cast<uint32_t*>(q + o) = pack4_i8(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (seg * 4 + k < static_cast<uint32_t>(Wf)) q[o + k] = static_cast<int8_t>(static_cast<int>(v[k]));
+        }
+    }
+}
+
 int parts_for(int64_t n) {
     const int64_t want = ceil_div(n, static_cast<int64_t>(kBlock) * 32);   // >= 32 elements per thread
     return static_cast<int>(want < 1 ? 1 : want > kMaxParts ? kMaxParts : want);
@@ -208,4 +377,89 @@ extern "C" int miq_dynamic_epilogue_i8(const float* min_max, const float* w_scal
     dynamic_epilogue_kernel<<<static_cast<int>(blocks < 1024 ? blocks : 1024), kBlock, 0, as_stream(stream)>>>(
         min_max, w_scale, bias, w_rowsum, n, scale_zp, alpha, corr);
     return check_launch("dynamic_epilogue_kernel");
+}
+
+extern "C" size_t miq_dynamic_quant_workspace(int64_t n) {
+    return n > 0 ? static_cast<size_t>(parts_for(n)) * 2 * sizeof(float) : 0;
+}
+
+extern "C" int miq_dynamic_quant_params_i8(const void* x, int x_dtype, int64_t n, const float* w_scale, const float* bias,
+                                           const float* w_rowsum, int64_t channels, float* scale_zp, float* alpha, float* corr,
+                                           void* workspace, size_t workspace_bytes, unsigned* counter, void* stream) {
+    MIQ_REQUIRE(n > 0 && channels >= 0, MIQ_EINVAL, "miq_dynamic_quant_params_i8: the tensor is empty (n=%lld)", (long long)n);
+    MIQ_REQUIRE(x && scale_zp && counter && (channels == 0 || (w_scale && w_rowsum && alpha && corr)), MIQ_EINVAL,
+                "miq_dynamic_quant_params_i8: null pointer");
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_dynamic_quant_params_i8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    MIQ_REQUIRE(aligned(x, x_dtype == MIQ_F32 ? 4 : 2) && aligned(scale_zp, 4) && aligned(counter, 4) && aligned(w_scale, 4) &&
+                    aligned(bias, 4) && aligned(w_rowsum, 4) && aligned(alpha, 4) && aligned(corr, 4),
+                MIQ_EALIGN, "miq_dynamic_quant_params_i8: pointers must be aligned to their element size");
+    const size_t need = miq_dynamic_quant_workspace(n);
+    MIQ_REQUIRE(workspace && workspace_bytes >= need && aligned(workspace, 4), MIQ_EWORKSPACE,
+                "miq_dynamic_quant_params_i8: this call needs %zu bytes of 4-byte aligned workspace (got %zu)", need,
+                workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    float* parts = static_cast<float*>(workspace);
+    const int nparts = parts_for(n);
+    const bool vec = aligned(x, 16);
+#define MIQ_PARAMS(DT)                                                                                                       \
+    do {                                                                                                                     \
+        if (vec)                                                                                                             \
+            dynamic_params_kernel<DT, true><<<nparts, kBlock, 0, st>>>(x, n, parts, counter, w_scale, bias, w_rowsum, channels, \
+                                                                       scale_zp, alpha, corr);                              \
+        else                                                                                                                 \
+            dynamic_params_kernel<DT, false><<<nparts, kBlock, 0, st>>>(x, n, parts, counter, w_scale, bias, w_rowsum, channels, \
+                                                                        scale_zp, alpha, corr);                             \
+    } while (0)
+    switch (x_dtype) {
+        case MIQ_F32: MIQ_PARAMS(MIQ_F32); break;
+        case MIQ_F16: MIQ_PARAMS(MIQ_F16); break;
+        default: MIQ_PARAMS(MIQ_BF16); break;
+    }
+#undef MIQ_PARAMS
+    return check_launch("dynamic_params_kernel");
+}
+
+extern "C" int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes, int64_t H, int64_t W, int64_t pad_top,
+                                      int64_t pad_bottom, int64_t pad_left, int64_t pad_right, const float* scale_zp, int8_t* q,
+                                      void* stream) {
+    MIQ_REQUIRE(planes >= 0 && H >= 0 && W >= 0 && pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 && pad_right >= 0, MIQ_EINVAL,
+                "miq_quantize_tensor_i8: negative size");
+    MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
+                "miq_quantize_tensor_i8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    const int64_t Hf = H + pad_top + pad_bottom, Wf = W + pad_left + pad_right;
+    if (planes * Hf * Wf == 0) return MIQ_OK;
+    MIQ_REQUIRE(scale_zp && q && (x || planes * H * W == 0), MIQ_EINVAL, "miq_quantize_tensor_i8: null pointer");
+    MIQ_REQUIRE(aligned(x, x_dtype == MIQ_F32 ? 4 : 2) && aligned(scale_zp, 4), MIQ_EALIGN,
+                "miq_quantize_tensor_i8: x / scale_zp not aligned to their element size");
+    hipStream_t st = as_stream(stream);
+    const bool framed = pad_top || pad_bottom || pad_left || pad_right;
+    if (!framed) {
+        const int64_t n = planes * H * W;
+        const int per = x_dtype == MIQ_F32 ? 4 : 8;
+        const int vector = aligned(x, 16) && aligned(q, per);
+        const int64_t blocks = ceil_div(ceil_div(n, per), kBlock);
+        const int grid = static_cast<int>(blocks < 1 ? 1 : blocks > 8192 ? 8192 : blocks);
+        switch (x_dtype) {
+            case MIQ_F32: quantize_tensor_kernel<MIQ_F32><<<grid, kBlock, 0, st>>>(x, n, scale_zp, q, vector); break;
+            case MIQ_F16: quantize_tensor_kernel<MIQ_F16><<<grid, kBlock, 0, st>>>(x, n, scale_zp, q, vector); break;
+            default: quantize_tensor_kernel<MIQ_BF16><<<grid, kBlock, 0, st>>>(x, n, scale_zp, q, vector); break;
+        }
+        return check_launch("quantize_tensor_kernel");
+    }
+    MIQ_REQUIRE(planes * Hf < (1ll << 32) && Hf < (1ll << 31) && Wf < (1ll << 31) && H < (1ll << 31) && W < (1ll << 31), MIQ_ERANGE,
+                "miq_quantize_tensor_i8: at most 2^32 output rows");
+    const int64_t items = planes * Hf * ceil_div(Wf, 4);
+    const int64_t blocks = ceil_div(items, kBlock);
+    const int grid = static_cast<int>(blocks > 16384 ? 16384 : blocks);
+#define MIQ_FRAMED(DT)                                                                                                      \
+    quantize_framed_kernel<DT><<<grid, kBlock, 0, st>>>(x, static_cast<uint32_t>(planes * Hf), (int)H, (int)W, (int)pad_top, \
+                                                        (int)pad_left, (int)Hf, (int)Wf, scale_zp, q)
+    switch (x_dtype) {
+        case MIQ_F32: MIQ_FRAMED(MIQ_F32); break;
+        case MIQ_F16: MIQ_FRAMED(MIQ_F16); break;
+        default: MIQ_FRAMED(MIQ_BF16); break;
+    }
+#undef MIQ_FRAMED
+    return check_launch("quantize_framed_kernel");
 }

@@ -286,8 +286,10 @@ class WeightOnlyQuantizer(_QuantizerBase):
             bias = None if self.bias is None else _to_gpu(self.bias.detach())
             xg = _to_gpu(x).to(torch.float32)
             if self.cnn:
+                plain = _plain_conv(self.stride, self.padding, self.dilation, self.groups)
                 y = conv2d_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum, self.stride, self.padding,
-                                        dilation=self.dilation, groups=self.groups)
+                                        dilation=self.dilation, groups=self.groups,
+                                        packed=self._packed(w, torch.int8) if plain else None)
             else:
                 y = linear_dynamic_w8a8(xg, w, _to_gpu(wq.scales), bias, self._rowsum)
             return y.to(home)

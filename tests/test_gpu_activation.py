@@ -165,3 +165,91 @@ def test_activation_entry_points_reject_bad_arguments():
     assert lib.miq_pool2d_to_i8(p(x), 0, 1, 1, 4, 4, 2, 2, 2, 2, 0, 0, 5, p(ws), None) == -1   # unknown mode
     assert lib.miq_pool2d_to_i8(p(x), 3, 1, 1, 4, 4, 2, 2, 2, 2, 0, 0, 0, p(ws), None) == -1   # int32 input
     assert lib.miq_pool2d_to_i8(p(x), 0, 1, 1, 4, 4, 2, 2, 0, 2, 0, 0, 0, p(ws), None) == -1   # zero stride
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(7,), (64, 300), (1025, 4099), (4096, 8192)])
+def test_one_launch_parameters_equal_the_separate_calls(dtype, shape):
+    """miq_dynamic_quant_params_i8 (statistics, parameters and epilogue vectors in one launch, the last workgroup to
+    arrive finishing the reduction) against the three-call form it replaces, bit for bit; the counter word it counts
+    workgroups in is left zero, so the next call (here: repeated, and on an unaligned view) starts clean."""
+    from quantization_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 1)
+    x = (torch.randn(shape, generator=g, device="cuda") * 3 - 0.5).to(dtype)
+    n = 300
+    w_scale = torch.rand(n, generator=g, device="cuda") * 0.01 + 1e-4
+    bias = torch.randn(n, generator=g, device="cuda")
+    rowsum = torch.randint(-5000, 5000, (n,), generator=g, device="cuda").float()
+    for rep in range(3):
+        xx = x if rep < 2 or x.numel() < 10 else torch.as_strided(x.reshape(-1), (x.numel() - 1,), (1,), 1)
+        ref_szp, ref_alpha, ref_corr = N.dynamic_epilogue_i8(N.tensor_minmax(xx), w_scale, bias, rowsum)
+        szp, alpha, corr = N.dynamic_quant_params(xx, w_scale, bias, rowsum)
+        assert torch.equal(szp[:2], ref_szp) and torch.equal(alpha, ref_alpha) and torch.equal(corr, ref_corr)
+        assert int(szp[2:3].view(torch.int32)) == int(ref_szp[1])
+        assert int(N._counter(x.device)) == 0
+    szp2, a2, c2 = N.dynamic_quant_params(x)          # statistics and parameters only
+    assert a2 is None and c2 is None and torch.equal(szp2[:2], N.dynamic_epilogue_i8(N.tensor_minmax(x), w_scale, None, rowsum)[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,pad", [((2, 3, 5, 7), (1, 1, 1, 1)), ((1, 4, 8, 8), (0, 2, 3, 0)), ((3, 16, 14, 14), (1, 1, 1, 1)),
+                                       ((2, 5, 9, 13), (2, 1, 0, 3)), ((4, 8, 12, 12), (0, 0, 0, 0)), ((1, 1, 3, 1), (3, 3, 3, 3))])
+def test_quantize_tensor_into_a_frame_of_zero_points(dtype, shape, pad):
+    """miq_quantize_tensor_i8: the interior equals the row-parameter entry point (miq_quantize_rows_given_i8, itself
+    pinned to the oracle), and for fp32 the oracle's formula directly; the frame holds the zero point."""
+    from quantization_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g, device="cuda") * 2 + 0.8).to(dtype)
+    szp, _, _ = N.dynamic_quant_params(x)
+    q = N.quantize_tensor_i8(x, szp, pad)
+    pt, pb, pl, pr = pad
+    B, C, H, W = shape
+    assert tuple(q.shape) == (B, C, H + pt + pb, W + pl + pr)
+    inner = q[:, :, pt:pt + H, pl:pl + W]
+    ref = N.quantize_rows_given_i8(x.reshape(B * C, H * W), szp[0:1], szp[1:2]).view(B, C, H, W)
+    assert torch.equal(inner, ref)
+    if dtype == torch.float32:
+        rq, rs, rzp = O.quantize_tensor_affine_int8(x.cpu().numpy())
+        np.testing.assert_array_equal(inner.cpu().numpy(), rq)
+        assert float(szp[0]) == float(rs[0]) and int(szp[1]) == int(rzp[0])
+    frame = torch.ones_like(q, dtype=torch.bool)
+    frame[:, :, pt:pt + H, pl:pl + W] = False
+    assert bool((q[frame] == int(szp[1])).all())
+
+
+def test_conv2d_dynamic_w8a8_takes_one_image():
+    """An unbatched [C, H, W] image, as F.conv2d takes it: the batched result of the same image."""
+    from quantization_amd import _native as Nv
+    from quantization_amd.activation import conv2d_dynamic_w8a8
+    g = torch.Generator(device="cuda").manual_seed(2)
+    w = torch.randn(8, 5, 3, 3, generator=g, device="cuda") * 0.05
+    x = torch.randn(5, 11, 9, generator=g, device="cuda") + 0.4
+    wq, ws, _ = Nv.quantize_rows_sym_i8(w.view(8, -1))
+    wq = wq.view(8, 5, 3, 3)
+    y1 = conv2d_dynamic_w8a8(x, wq, ws, None, stride=1, padding=1)
+    yb = conv2d_dynamic_w8a8(x.unsqueeze(0), wq, ws, None, stride=1, padding=1)
+    assert y1.dim() == 3 and torch.equal(y1, yb[0])
+
+
+def test_new_activation_entry_points_reject_bad_arguments():
+    import ctypes
+    from quantization_amd import _native as N
+    lib = N.lib()
+    x = torch.zeros(1024, device="cuda")
+    out = torch.zeros(4, device="cuda")
+    ws = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    q = torch.zeros(2048, dtype=torch.int8, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    f = lib.miq_dynamic_quant_params_i8
+    assert f(p(x), 0, 0, None, None, None, 0, p(out), None, None, p(ws), 64, p(cnt), None) == -1        # empty tensor
+    assert f(p(x), 0, 1024, None, None, None, 0, p(out), None, None, p(ws), 64, None, None) == -1       # no counter
+    assert f(p(x), 0, 1024, None, None, None, 4, p(out), None, None, p(ws), 64, p(cnt), None) == -1     # channels without vectors
+    assert f(p(x), 9, 1024, None, None, None, 0, p(out), None, None, p(ws), 64, p(cnt), None) == -1     # unknown dtype
+    assert f(p(x), 0, 1024, None, None, None, 0, p(out), None, None, None, 0, p(cnt), None) == -3       # no workspace
+    g = lib.miq_quantize_tensor_i8
+    assert g(p(x), 0, 1, 32, 32, -1, 0, 0, 0, p(out), p(q), None) == -1                                # negative padding
+    assert g(p(x), 0, 1, 32, 32, 0, 0, 0, 0, None, p(q), None) == -1                                   # no parameters
+    assert g(p(x), 5, 1, 32, 32, 0, 0, 0, 0, p(out), p(q), None) == -1                                 # unknown dtype
+    assert g(p(x), 0, 0, 32, 32, 1, 1, 1, 1, p(out), p(q), None) == 0                                  # nothing to do
+    assert int(cnt) == 0
