@@ -228,7 +228,13 @@ __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x
 __device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H, int W, int Hp, int Wp, int Cp, int pad,
                                                   uint32_t total, uint32_t first, uint32_t step, int64_t plane_stride = 0) {
     const uint32_t per_image = 2 * pad * Wp + 2 * pad * H;   // border pixels of one image
-    for (uint32_t idx = first; idx < total; idx += step) {
+    // An item is one 16-byte chunk of one border pixel where pixels are whole chunks (neighbouring lanes then write
+    // neighbouring chunks: a pixel of 512 channels is 32 lanes' one store each, not one lane's 32), else a whole pixel.
+    const bool chunked = plane_stride != 0 || (Cp & 15) == 0;
+    const uint32_t cpp = chunked ? static_cast<uint32_t>(Cp >> 4) : 1u;   // items per pixel
+    const uint64_t items = static_cast<uint64_t>(total) * cpp;
+    for (uint64_t it = first; it < items; it += step) {
+        const uint32_t idx = static_cast<uint32_t>(it / cpp), c = static_cast<uint32_t>(it - static_cast<uint64_t>(idx) * cpp);
         const uint32_t b = idx / per_image, e = idx - b * per_image;
         uint32_t hp, wp;
         if (e < static_cast<uint32_t>(2 * pad * Wp)) {   // full rows: the first `pad` and the last `pad`
@@ -242,11 +248,11 @@ __device__ __forceinline__ void nhwc_border_items(int8_t* __restrict__ xp, int H
         }
         const int64_t pix = (static_cast<int64_t>(b) * Hp + hp) * Wp + wp;
         if (plane_stride) {
-            for (int c = 0; c < (Cp >> 4); ++c) *reinterpret_cast<uint4*>(xp + c * plane_stride + pix * 16) = uint4{0u, 0u, 0u, 0u};
-        } else if ((Cp & 15) == 0) {
-            for (int c = 0; c < (Cp >> 4); ++c) reinterpret_cast<uint4*>(xp + pix * Cp)[c] = uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4*>(xp + c * plane_stride + pix * 16) = uint4{0u, 0u, 0u, 0u};
+        } else if (chunked) {
+            reinterpret_cast<uint4*>(xp + pix * Cp)[c] = uint4{0u, 0u, 0u, 0u};
         } else {
-            for (int c = 0; c < (Cp >> 2); ++c) reinterpret_cast<uint32_t*>(xp + pix * Cp)[c] = 0u;
+            for (int k = 0; k < (Cp >> 2); ++k) reinterpret_cast<uint32_t*>(xp + pix * Cp)[k] = 0u;
         }
     }
 }
@@ -1955,7 +1961,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
             pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.pitch + 2 * pad * H));
             pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
-            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
+            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) * (Cin / 16) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if ((H * W) % 4 == 0 && miq::aligned(x, 4))
@@ -1977,8 +1983,8 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
             pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             pa.sub = (int)G.sub; pa.Ws = (int)G.Ws; pa.HWs = (int)(G.Hs * G.Ws);
-            // about four border pixels / weight dwords per extra thread, spread over the images' grid rows
-            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
+            // about four border chunks / weight dwords per extra thread, spread over the images' grid rows
+            const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) * ((G.Cp & 15) ? 1 : G.Cp / 16) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
             if (G.sub == 2 && W % 4 == 0 && G.Ws % 4 == 0 && (G.Hs * G.Ws) % 8 == 0 && miq::aligned(x, 8))
@@ -2174,7 +2180,7 @@ int conv2d_i8_dense(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, in
     pa.border_total = static_cast<uint32_t>(B * (2 * G.P * G.Wp + 2 * G.P * H));
     pa.weight_total = static_cast<uint32_t>(G.wp_bytes / 4);
     pa.sub = 1; pa.Ws = (int)W; pa.HWs = (int)(H * W);
-    const int64_t extra = ceil_div(static_cast<int64_t>(pa.border_total) + pa.weight_total, 1024);
+    const int64_t extra = ceil_div(static_cast<int64_t>(pa.border_total) * ((G.Cp & 15) ? 1 : G.Cp / 16) + pa.weight_total, 1024);
     pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(ceil_div(extra, B), 1), 4096));
     dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
     if ((H * W) % 4 == 0 && aligned(x, 4))
