@@ -272,6 +272,9 @@ class WeightOnlyQuantizer(_QuantizerBase):
         if not (wq.symmetric and wq.dtype == torch.int8):
             # zero_point is identically 0 for symmetric int8, the only form quantize() produces
             raise NotImplementedError("only symmetric int8 weights are implemented")
+        grp = self.__dict__.get("_sibling_group")
+        if grp is not None and not self.input_quant and grp[0].usable(x):
+            return grp[0].output(x, grp[1])   # this layer's columns of the one product its siblings share
         if self.input_quant and x.dtype.is_floating_point:
             # The step the reference leaves commented out (Quantizer.py:69-70): quantize the activation per
             # tensor and take the int8 product (see quantization_amd/activation.py; a convolution's padding
@@ -328,6 +331,113 @@ class WeightOnlyQuantizer(_QuantizerBase):
         return self._repr(details)
 
 
+
+class SiblingGroup:
+    """Weight-only quantized Linear layers that multiply the SAME activation (the gate and up projections of an MLP, the
+    q / k / v projections of an attention block), stored as ONE [sum N_i, K] int8 weight and run as ONE product: at decode
+    sizes a layer's time is its weight read plus a fixed few microseconds per launch, so n layers in one launch save n - 1
+    of those (Llama-3-8B gate + up at one token: 2 x 14.4 us -> 24.6 us).  Per-channel scales and biases make the fused
+    product the concatenation of the separate ones bit for bit: no accumulation order changes.
+
+    The member layers keep their place in the model and their interface.  Their `weight` buffers become row blocks
+    (views) of the fused weight, so nothing is stored twice and state_dict() is unchanged.  The first member called on an
+    activation computes the whole product; the others, called on the same tensor, take their columns of it.  A member whose
+    weight has been moved or replaced since (so that it is no longer a view of the fused weight) runs on its own again."""
+
+    def __init__(self, layers):
+        layers = list(layers)
+        if len(layers) < 2:
+            raise ValueError("a group needs at least two layers")
+        for m in layers:
+            if not isinstance(m, WeightOnlyQuantizer) or m.cnn:
+                raise TypeError("only weight-only quantized Linear layers can be fused")
+            if m._params_stale:
+                raise RuntimeError(m._params_stale)
+            if m.in_features != layers[0].in_features:
+                raise ValueError("fused layers must have the same in_features")
+            if m.__dict__.get("_sibling_group") is not None:
+                raise ValueError("a layer can belong to one group only")
+        self.layers = layers
+        self.splits = [m.out_features for m in layers]
+        weight = torch.cat([_to_gpu(m.weight.detach()) for m in layers], dim=0).contiguous()
+        self.weight = weight
+        self.alpha = torch.cat([_to_gpu(m.weight_quant.scales.detach()).reshape(-1).to(torch.float32) for m in layers]).contiguous()
+        if any(m.bias is not None for m in layers):
+            self.bias = torch.cat([(_to_gpu(m.bias.detach()).reshape(-1).to(torch.float32) if m.bias is not None
+                                    else torch.zeros(m.out_features, dtype=torch.float32, device=weight.device))
+                                   for m in layers]).contiguous()
+        else:
+            self.bias = None
+        lo = 0
+        for i, m in enumerate(layers):
+            m.weight = weight[lo:lo + m.out_features]          # a view: the fused weight is the only copy
+            m._invalidate()
+            m.__dict__["_sibling_group"] = (self, i)
+            lo += m.out_features
+        self._ptrs = [m.weight.data_ptr() for m in layers]
+        self._last = None     # (activation, its version, outputs, members still to collect)
+
+    def usable(self, x):
+        """The fused weight still is what every member holds (none was moved, replaced or re-quantized), and x is one
+        the fused kernels take."""
+        return (all(m.weight.data_ptr() == p and not m._params_stale for m, p in zip(self.layers, self._ptrs))
+                and (x.dtype == torch.int8 or x.dtype.is_floating_point))
+
+    @torch.no_grad()
+    def output(self, x, index):
+        c = self._last
+        if c is None or c[0] is not x or c[1] != x._version or index not in c[3]:
+            home = x.device
+            xd = _to_gpu(x).contiguous()
+            lead = xd.shape[:-1]
+            x2 = xd.reshape(-1, xd.shape[-1])
+            if xd.dtype == torch.int8:
+                y = _native.gemm_i8(x2, self.weight, bias=self.bias, alpha=self.alpha, beta=0.0)
+            else:
+                if xd.dtype == torch.float64:
+                    x2 = x2.to(torch.float32)
+                y = _native.gemm_w8(x2.contiguous(), self.weight, bias=self.bias, alpha=self.alpha, beta=0.0)
+            outs = torch.split(y.view(*lead, y.shape[-1]).to(home), self.splits, dim=-1)
+            c = self._last = (x, x._version, outs, set(range(len(self.layers))))
+        c[3].discard(index)
+        out = c[2][index]
+        if not c[3]:
+            self._last = None     # every member has its columns: let go of the activation and the product
+        return out
+
+
+def fuse_linear_siblings(parent, names):
+    """Fuse the weight-only quantized Linear layers `names` of `parent` (they must read the same activation: the caller
+    says so) into one stored weight and one product per forward.  Returns the SiblingGroup."""
+    return SiblingGroup([getattr(parent, n) for n in names])
+
+
+def fuse_shared_inputs(model, *example_inputs, **example_kwargs):
+    """Find the weight-only quantized Linear layers of `model` that are called on the very same tensor during one forward
+    pass on the example inputs, and fuse each such set.  Returns the list of groups."""
+    seen, hooks = {}, []
+
+    def hook(module, inputs):
+        if inputs and isinstance(inputs[0], torch.Tensor):
+            seen.setdefault(id(inputs[0]), (inputs[0], []))[1].append(module)
+
+    for m in model.modules():
+        if isinstance(m, WeightOnlyQuantizer) and not m.cnn and m.__dict__.get("_sibling_group") is None:
+            hooks.append(m.register_forward_pre_hook(hook))
+    try:
+        with torch.no_grad():
+            model(*example_inputs, **example_kwargs)
+    finally:
+        for h in hooks:
+            h.remove()
+    groups = []
+    for _, mods in seen.values():
+        uniq = list(dict.fromkeys(mods))
+        if len(uniq) >= 2 and len({m.in_features for m in uniq}) == 1:
+            groups.append(SiblingGroup(uniq))
+    return groups
+
+
 class WeightOnlyChunker:
     """quant/Weight_Only/Chunker.py: swap every Conv2d / Linear for a quantized layer.
 
@@ -359,6 +469,11 @@ class WeightOnlyChunker:
 
     def chunk(self):
         self.weight_quantize()
+
+    def fuse_siblings(self, *example_inputs, **example_kwargs):
+        """After the rewrite: fuse the quantized Linear layers that one forward pass on the example inputs calls on the
+        same tensor (see SiblingGroup).  Has no counterpart in the reference, whose layers each run their own product."""
+        return fuse_shared_inputs(self.model, *example_inputs, **example_kwargs)
 
 
 # =====================================================================================

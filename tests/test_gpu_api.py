@@ -349,3 +349,61 @@ def test_layer_forward_enqueues_only_and_captures_into_a_graph(wa, wo):
     # replacing the zero point is seen (the cache is keyed on the tensor, not on the layer)
     qa.output_zero_point = torch.tensor([-1.0]).cuda()
     assert torch.allclose(qa(x).double(), ref - 4.5, rtol=1e-5, atol=1e-5)
+
+
+class _GatedMLP(torch.nn.Module):
+    def __init__(self, d, h, bias):
+        super().__init__()
+        self.gate_proj = torch.nn.Linear(d, h, bias=bias)
+        self.up_proj = torch.nn.Linear(d, h + 64, bias=False)
+        self.down_proj = torch.nn.Linear(h, d, bias=bias)
+
+    def forward(self, x):
+        g, u = self.gate_proj(x), self.up_proj(x)
+        return self.down_proj(torch.nn.functional.silu(g.float()) * u[..., :g.shape[-1]].float()), g, u
+
+
+@pytest.mark.parametrize("kind", ["int8", "float32", "bfloat16"])
+def test_sibling_layers_fused_into_one_product(kind):
+    """Chunker.fuse_siblings(): the gate and up projections of an MLP (called on the same tensor) become one stored weight
+    and one product; each layer's output equals the unfused layer's bit for bit, which for int8 activations is the
+    oracle's (exact int32 product + the reference's epilogue order).  The layers keep their interface, state_dict keys and
+    values; a member moved off the fused weight runs on its own again."""
+    from quantization_amd.qlayers import SiblingGroup
+    from quantization_amd.quant.Weight_Only.Chunker import Chunker
+    torch.manual_seed(11)
+    model = _GatedMLP(256, 320, bias=True).cuda()
+    ck = Chunker(model, None)
+    g = torch.Generator().manual_seed(5)
+    if kind == "int8":
+        x = torch.randint(-128, 128, (3, 5, 256), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    else:
+        x = torch.randn(3, 5, 256, generator=g).to(getattr(torch, kind)).cuda()
+    y_ref, g_ref, u_ref = model(x if kind != "int8" else x)
+    sd_ref = {k: v.clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+    groups = ck.fuse_siblings(x)
+    assert len(groups) == 1 and isinstance(groups[0], SiblingGroup)
+    assert {id(m) for m in groups[0].layers} == {id(model.gate_proj), id(model.up_proj)}
+    assert model.gate_proj.weight.untyped_storage().data_ptr() == model.up_proj.weight.untyped_storage().data_ptr()
+    y, gq, uq = model(x)
+    assert torch.equal(gq, g_ref) and torch.equal(uq, u_ref) and torch.equal(y, y_ref)
+    assert tuple(gq.shape) == (3, 5, 320) and tuple(uq.shape) == (3, 5, 384)
+    if kind == "int8":
+        from oracle import oracle_np as O
+        wq, s = model.gate_proj.weight.cpu().numpy(), model.gate_proj.weight_quant.scales.reshape(-1).cpu().numpy()
+        ref = O.wo_linear_forward(x.reshape(-1, 256).cpu().numpy(), wq, s, model.gate_proj.bias.detach().cpu().numpy())
+        np.testing.assert_array_equal(gq.reshape(-1, 320).cpu().numpy(), ref)
+    # a second activation: nothing stale is served
+    x2 = x.clone()
+    x2[0, 0, :8] = 1
+    g2, u2 = model.gate_proj(x2), model.up_proj(x2)
+    assert not torch.equal(g2, gq) and torch.equal(model.gate_proj(x), gq) and torch.equal(model.up_proj(x), uq)
+    assert torch.equal(u2, model.up_proj(x2))
+    # the same state_dict as before fusing
+    sd = model.state_dict()
+    for k, v in sd_ref.items():
+        assert torch.equal(sd[k], v), k
+    # a member that leaves the fused weight (here: re-created buffers) runs on its own, same result
+    model.up_proj.weight = model.up_proj.weight.clone()
+    assert not groups[0].usable(x)
+    assert torch.equal(model.up_proj(x), uq) and torch.equal(model.gate_proj(x), gq)
