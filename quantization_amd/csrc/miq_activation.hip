@@ -7,6 +7,7 @@
 #include <hip/hip_fp16.h>
 
 #include "miq_common.h"
+#include "miq_gemm_core.h"
 
 namespace {
 
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(kBlock) void dynamic_epilogue_kernel(const float* _
 // ---------------------------------------------------------------------------------------
 // The dynamic activation quantizer in two launches.
 //
-// dynamic_params_kernel: every workgroup leaves the (min, max) of its share of x in `parts` and takes a ticket from
-// `counter` (a device-scope atomic behind a device-scope fence, so that its pair is visible to whoever reads the
-// counter after it).  The workgroup that draws the last ticket folds the pairs, derives the per-tensor affine
+// dynamic_params_kernel: every workgroup leaves the (min, max) of its share of x in `parts` (device-scope stores) and
+// takes a ticket from `counter` (a device-scope atomic, after its stores have completed: see store_shared in
+// miq_gemm_core.h).  The workgroup that draws the last ticket folds the pairs, derives the per-tensor affine
 // parameters (Qop.calculate_params, quant/Weight_Only/Qop.py:40-41, 62-65) and, for a weight-only layer, the epilogue
 // vectors of its int8 product, and sets the counter back to zero: one launch where the statistics, the parameters and
 // the vectors took three.  quantize_tensor_kernel then applies Qop.py:157 with those parameters, optionally into the
@@ -198,21 +199,16 @@ __global__ __launch_bounds__(kBlock) void dynamic_params_kernel(const void* __re
         }
     }
     block_minmax(lo, hi);
-    __shared__ unsigned ticket;
-    if (threadIdx.x == 0) {
-        parts[2 * blockIdx.x] = lo;
-        parts[2 * blockIdx.x + 1] = hi;
-        __threadfence();                        // the pair is visible device-wide before the ticket is taken
-        ticket = atomicAdd(counter, 1u);
+    if (threadIdx.x == 0) {                     // device-scope stores: visible to whoever draws the last ticket
+        store_shared(parts + 2 * blockIdx.x, lo);
+        store_shared(parts + 2 * blockIdx.x + 1, hi);
     }
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;        // (uniform over the workgroup)
-    __threadfence();                            // ... and every earlier workgroup's pair is visible to this one
+    if (take_ticket(counter) != gridDim.x - 1) return;   // (uniform over the workgroup)
     lo = INFINITY;
     hi = -INFINITY;
     for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += kBlock) {
-        lo = fminf(lo, __builtin_nontemporal_load(parts + 2 * i));
-        hi = fmaxf(hi, __builtin_nontemporal_load(parts + 2 * i + 1));
+        lo = fminf(lo, load_shared(parts + 2 * i));
+        hi = fmaxf(hi, load_shared(parts + 2 * i + 1));
     }
     __syncthreads();                            // block_minmax's LDS words are read by every thread above
     block_minmax(lo, hi);
@@ -225,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void dynamic_params_kernel(const void* __re
         scale_zp[0] = scale;
         scale_zp[1] = zp;
         scale_zp[2] = __int_as_float(static_cast<int>(zp));   // the zero point as int32 bits (Qop keeps an integer tensor)
-        *counter = 0u;                                        // ready for the next call
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
     }
     for (int64_t i = threadIdx.x; i < nch; i += kBlock) {
         alpha[i] = __fmul_rn(w_scale[i], scale);

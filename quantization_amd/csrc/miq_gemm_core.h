@@ -66,6 +66,51 @@ __device__ __forceinline__ int frag_lane_offset(int lane, int ks) {
 
 __device__ __forceinline__ v4i lds_read16(const char* p) { return *reinterpret_cast<const v4i*>(p); }
 
+// Data that one workgroup hands to another inside a launch (partial results behind an arrival counter).  The eight XCDs
+// have an L2 each, so ordinary stores may sit in the writer's L2 and ordinary loads may hit stale lines of the reader's:
+// making them visible with device-scope FENCES works but writes back and invalidates a whole L2 per fence (measured: a
+// split-K GEMM ran 4-5x slower).  Instead the hand-over data itself moves with device-scope relaxed atomic stores and
+// loads (written through to / read from the level all XCDs share), the writer waits for its stores to complete
+// (s_waitcnt vmcnt(0)) before it takes its ticket with a device-scope atomic add, and the reader loads after it has seen
+// the last ticket.  Nothing else is flushed.
+__device__ __forceinline__ void store_shared(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_shared(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int load_shared(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_shared(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// four int32 at an 8-byte aligned address, as two 64-bit accesses
+__device__ __forceinline__ void store_shared4(int* p, v4i v) {
+    typedef unsigned long long u64;
+    u64* q = reinterpret_cast<u64*>(p);
+    __hip_atomic_store(q, static_cast<u64>(static_cast<uint32_t>(v[0])) | (static_cast<u64>(static_cast<uint32_t>(v[1])) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, static_cast<u64>(static_cast<uint32_t>(v[2])) | (static_cast<u64>(static_cast<uint32_t>(v[3])) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ v4i load_shared4(const int* p) {
+    typedef unsigned long long u64;
+    const u64* q = reinterpret_cast<const u64*>(p);
+    const u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v4i{static_cast<int>(a), static_cast<int>(a >> 32), static_cast<int>(b), static_cast<int>(b >> 32)};
+}
+// Every store this wave issued has completed; then the workgroup's.  Returns the ticket thread 0 drew from `counter`.
+__device__ __forceinline__ unsigned take_ticket(unsigned* counter) {
+    __shared__ unsigned ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return ticket;
+}
+
 // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs, so
 // ids b, b+8, ... share an L2.  Give each XCD a contiguous range of tile ids (bijective for
 // any grid size), then walk that range in bands of `group` tile-rows so that the tiles in

@@ -194,3 +194,34 @@ def test_two_ranks_on_one_gpu_real_gemm(tmp_path):
     ref2 = O.wo_linear_forward(z["x"], q2, s2, None)
     np.testing.assert_array_equal(z["ragged"], ref2)
     np.testing.assert_array_equal(z["ragged_t"], ref2)
+
+
+def test_split_k_repeated_on_two_streams_and_inside_a_graph(N):
+    """Thin problems are cut along K into int32 slabs that a second launch sums: called repeatedly, on two streams, and
+    recorded into a HIP graph that is replayed, the result stays the oracle's."""
+    M, Nn, K = 40, 520, 8192
+    a, w, alpha, bias, acc = operands(M, Nn, K)
+    ref = OC.epilogue_f32(acc, bias.numpy(), alpha.numpy(), 0.0)
+    ad, wd, al, bi = a.cuda(), w.cuda(), alpha.cuda(), bias.cuda()
+    out = torch.empty(M, Nn, device="cuda")
+    for _ in range(3):
+        out.zero_()
+        N.gemm_i8(ad, wd, bias=bi, alpha=al, out=out)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out2 = N.gemm_i8(ad, wd, bias=bi, alpha=al)
+    out3 = N.gemm_i8(ad, wd, bias=bi, alpha=al)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out2.cpu().numpy(), ref)
+    np.testing.assert_array_equal(out3.cpu().numpy(), ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        N.gemm_i8(ad, wd, bias=bi, alpha=al, out=out)
+        N.gemm_i8(ad, wd, bias=bi, alpha=al, out=out)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
