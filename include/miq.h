@@ -358,6 +358,27 @@ int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes, int64_t H
                            int64_t pad_bottom, int64_t pad_left, int64_t pad_right, const float* scale_zp, int8_t* q,
                            void* stream);
 
+/* miq_dynamic_quant_params_i8 followed by miq_quantize_tensor_i8 on the same tensor, as one call (two launches): the
+ * arguments of both (x is [planes, H, W], its statistics are taken over all planes * H * W elements). */
+int miq_dynamic_quantize_i8(const void* x, int x_dtype, int64_t planes, int64_t H, int64_t W, int64_t pad_top,
+                            int64_t pad_bottom, int64_t pad_left, int64_t pad_right, const float* w_scale, const float* bias,
+                            const float* w_rowsum, int64_t channels, float* scale_zp, float* alpha, float* corr, int8_t* q,
+                            void* workspace, size_t workspace_bytes, unsigned* counter, void* stream);
+
+/* A weight-only Linear on a floating-point activation through the int8 product, as ONE call (three launches:
+ * miq_dynamic_quant_params_i8, miq_quantize_tensor_i8, miq_gemm_i8 with alpha / corr as its epilogue vectors): what
+ * Quantizer.forward computes when the activation quantizer the reference configures (quant/Weight_Only/Quantizer.py:38-44,
+ * call sites commented out at :69-70) is switched on:
+ *     out[m,n] = w_scale[n] * (sum_k x_hat[m,k] * W[n,k] + bias[n]),  x_hat = scale * (q - zero_point) the activation as
+ *     its per-tensor affine int8 form represents it.
+ * x: [M,K] of x_dtype MIQ_F32 | MIQ_F16 | MIQ_BF16; W int8 [N,K]; w_rowsum[n] = sum_k W[n,k] as fp32 (once per layer);
+ * out: [M,N] of out_dtype MIQ_F32 | MIQ_BF16.  workspace: miq_linear_dynamic_w8a8_workspace(M, N, K) bytes, 256-byte
+ * aligned; counter: as for miq_dynamic_quant_params_i8. */
+size_t miq_linear_dynamic_w8a8_workspace(int64_t M, int64_t N, int64_t K);
+int miq_linear_dynamic_w8a8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
+                            const float* w_scale, const float* bias, const float* w_rowsum, void* out, int out_dtype,
+                            void* workspace, size_t workspace_bytes, unsigned* counter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

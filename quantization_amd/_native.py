@@ -69,6 +69,9 @@ SYMBOLS = {
     "miq_dynamic_quant_workspace": (_size, [_i64]),
     "miq_dynamic_quant_params_i8": (_int, [_p, _int, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _size, _p, _p]),
     "miq_quantize_tensor_i8": (_int, [_p, _int] + [_i64] * 7 + [_p, _p, _p]),
+    "miq_dynamic_quantize_i8": (_int, [_p, _int] + [_i64] * 7 + [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _size, _p, _p]),
+    "miq_linear_dynamic_w8a8_workspace": (_size, [_i64] * 3),
+    "miq_linear_dynamic_w8a8": (_int, [_p, _int, _p] + [_i64] * 3 + [_p, _p, _p, _p, _int, _p, _size, _p, _p]),
 }
 
 _lib = None
@@ -335,6 +338,70 @@ def quantize_tensor_i8(x, scale_zp, pad=(0, 0, 0, 0)):
         _check(lib().miq_quantize_tensor_i8(_ptr(x), _FLOAT_CODES[x.dtype], planes, H, W, pt, pb, pl, pr, _ptr(scale_zp), _ptr(q),
                                             _stream()))
     return q
+
+
+def dynamic_quantize_i8(x, pad=(0, 0, 0, 0), w_scale=None, bias=None, w_rowsum=None):
+    """dynamic_quant_params + quantize_tensor_i8 as one call into the library (two launches): returns (q, scale_zp [3],
+    alpha, corr); pad frames the last two dimensions of x with the zero point."""
+    require_device(x, "tensor")
+    if x.dtype not in _FLOAT_CODES:
+        raise RuntimeError(f"tensor must be float32, float16 or bfloat16 (got {x.dtype})")
+    if x.numel() == 0:
+        raise RuntimeError("the tensor is empty")
+    dev = x.device
+    n = 0
+    if w_scale is not None:
+        n = w_scale.numel()
+        w_scale = _f32_vec(w_scale, n, "w_scale", dev)
+        w_rowsum = _f32_vec(w_rowsum, n, "w_rowsum", dev)
+        bias = _f32_vec(bias, n, "bias", dev)
+    pt, pb, pl, pr = (int(v) for v in pad)
+    if pt or pb or pl or pr:
+        H, W = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (H * W)
+        q = torch.empty((*x.shape[:-2], H + pt + pb, W + pl + pr), dtype=torch.int8, device=dev)
+    else:
+        planes, H, W = 1, 1, x.numel()
+        q = torch.empty(x.shape, dtype=torch.int8, device=dev)
+    L = lib()
+    need = L.miq_dynamic_quant_workspace(x.numel())
+    nf = 4 + 2 * n
+    buf = torch.empty(nf + (need + 3) // 4, dtype=torch.float32, device=dev)   # parameters, vectors and the workspace in one
+    scale_zp, alpha, corr = buf[:3], (buf[4:4 + n] if n else None), (buf[4 + n:nf] if n else None)
+    with _on(dev):
+        _check(L.miq_dynamic_quantize_i8(_ptr(x), _FLOAT_CODES[x.dtype], planes, H, W, pt, pb, pl, pr, _ptr(w_scale), _ptr(bias),
+                                         _ptr(w_rowsum), n, _ptr(scale_zp), _ptr(alpha), _ptr(corr), _ptr(q),
+                                         _p(buf.data_ptr() + 4 * nf), need, _ptr(_counter(dev)), _stream()))
+    return q, scale_zp, alpha, corr
+
+
+def linear_dynamic_w8a8(x, wq, w_scale, bias, w_rowsum, out_dtype=torch.float32):
+    """Weight-only Linear on a float activation x [M, K] through the int8 product with a per-tensor dynamic activation
+    quantizer: one call into the library (three launches), nothing on the host."""
+    require_device(x, "input")
+    require_device(wq, "weights")
+    if x.dtype not in _FLOAT_CODES or wq.dtype != torch.int8 or x.dim() != 2 or wq.dim() != 2 or x.shape[1] != wq.shape[1]:
+        raise RuntimeError(f"expected a float [M,K] input and an int8 [N,K] weight, got {tuple(x.shape)} {x.dtype} and "
+                           f"{tuple(wq.shape)} {wq.dtype}")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"unsupported output dtype {out_dtype}")
+    M, K = x.shape
+    n = wq.shape[0]
+    dev = x.device
+    w_scale = _f32_vec(w_scale, n, "w_scale", dev)
+    w_rowsum = _f32_vec(w_rowsum, n, "w_rowsum", dev)
+    bias = _f32_vec(bias, n, "bias", dev)
+    out = torch.empty((M, n), dtype=out_dtype, device=dev)
+    if M == 0 or n == 0:
+        return out
+    L = lib()
+    need = L.miq_linear_dynamic_w8a8_workspace(M, n, K)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _check(L.miq_linear_dynamic_w8a8(_ptr(x), _FLOAT_CODES[x.dtype], _ptr(wq), M, n, K, _ptr(w_scale), _ptr(bias),
+                                         _ptr(w_rowsum), _ptr(out), _OUT_CODES[out_dtype], _ptr(ws), need, _ptr(_counter(dev)),
+                                         _stream()))
+    return out
 
 
 def pool2d_to_i8(x, kernel_size, stride=None, padding=0, mode="max"):

@@ -42,9 +42,7 @@ def tensor_params_i8(x):
 @torch.no_grad()
 def quantize_tensor_i8(x):
     """x (float) -> (q int8 of x's shape, scale [1], zero_point [1]).  Two launches: statistics + parameters, quantize."""
-    x = x.contiguous()
-    scale_zp, _, _ = _native.dynamic_quant_params(x)
-    q = _native.quantize_tensor_i8(x, scale_zp)
+    q, scale_zp, _, _ = _native.dynamic_quantize_i8(x.contiguous())   # one call into the library
     return q, scale_zp[0:1], scale_zp[2:3].view(torch.int32)
 
 
@@ -64,9 +62,7 @@ def linear_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, out_dtype=torc
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     if w_rowsum is None:
         w_rowsum = weight_rowsum(wq)
-    scale_zp, alpha, corr = _native.dynamic_quant_params(x2, w_scale, bias, w_rowsum)
-    xq = _native.quantize_tensor_i8(x2, scale_zp)
-    y = _native.gemm_i8(xq, wq, bias=corr, alpha=alpha, beta=0.0, out_dtype=out_dtype)
+    y = _native.linear_dynamic_w8a8(x2, wq, w_scale, bias, w_rowsum, out_dtype)   # one call into the library
     return y.view(*lead, y.shape[-1])
 
 
@@ -88,8 +84,7 @@ def conv2d_dynamic_w8a8(x, wq, w_scale, bias=None, w_rowsum=None, stride=1, padd
     if w_rowsum is None:
         w_rowsum = weight_rowsum(wq)
     pad = _native.conv_padding(padding, wq.shape[2], wq.shape[3], stride, dilation)
-    scale_zp, alpha, corr = _native.dynamic_quant_params(x, w_scale.reshape(-1), bias, w_rowsum)
-    xq = _native.quantize_tensor_i8(x, scale_zp, pad)
+    xq, _, alpha, corr = _native.dynamic_quantize_i8(x, pad, w_scale.reshape(-1), bias, w_rowsum)
     sh, sw = _native._pair(stride)
     dh, dw = _native._pair(dilation)
     if sh == sw and dh == dw == 1 and groups == 1:

@@ -223,6 +223,29 @@ __global__ __launch_bounds__(kBlock) void dynamic_params_kernel(const void* __re
         scale_zp[2] = __int_as_float(static_cast<int>(zp));   // the zero point as int32 bits (Qop keeps an integer tensor)
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
     }
+    // the epilogue vectors: four channels a thread and step where the vectors are whole 16-byte groups, several steps'
+    // loads in flight (one workgroup does this for up to tens of thousands of channels: a dependent load per step
+    // would cost a memory round trip each)
+    const bool vec4 = (nch & 3) == 0 && ((reinterpret_cast<uintptr_t>(w_scale) | reinterpret_cast<uintptr_t>(w_rowsum) |
+                                          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(alpha) |
+                                          reinterpret_cast<uintptr_t>(corr)) & 15) == 0;
+    if (vec4) {
+        const int64_t n4 = nch >> 2;
+        const float4* ws4 = reinterpret_cast<const float4*>(w_scale);
+        const float4* rs4 = reinterpret_cast<const float4*>(w_rowsum);
+        const float4* b4 = reinterpret_cast<const float4*>(bias);
+#pragma unroll 4
+        for (int64_t i = threadIdx.x; i < n4; i += kBlock) {
+            const float4 w = ws4[i], r = rs4[i];
+            const float4 b = bias ? b4[i] : float4{0.f, 0.f, 0.f, 0.f};
+            reinterpret_cast<float4*>(alpha)[i] = float4{__fmul_rn(w.x, scale), __fmul_rn(w.y, scale), __fmul_rn(w.z, scale), __fmul_rn(w.w, scale)};
+            float4 c{__fmul_rn(-zp, r.x), __fmul_rn(-zp, r.y), __fmul_rn(-zp, r.z), __fmul_rn(-zp, r.w)};
+            if (bias) c = float4{__fadd_rn(c.x, b.x / scale), __fadd_rn(c.y, b.y / scale), __fadd_rn(c.z, b.z / scale), __fadd_rn(c.w, b.w / scale)};
+            reinterpret_cast<float4*>(corr)[i] = c;
+        }
+        return;
+    }
+#pragma unroll 4
     for (int64_t i = threadIdx.x; i < nch; i += kBlock) {
         alpha[i] = __fmul_rn(w_scale[i], scale);
         const float c = __fmul_rn(-zp, w_rowsum[i]);
@@ -317,7 +340,9 @@ __global__ __launch_bounds__(kBlock) void quantize_framed_kernel(const void* __r
 }
 
 int parts_for(int64_t n) {
-    const int64_t want = ceil_div(n, static_cast<int64_t>(kBlock) * 32);   // >= 32 elements per thread
+    // >= 16 elements per thread.  (More, smaller workgroups read a small tensor faster but then all finish together and
+    // queue on the arrival counter: 512 workgroups on a [256,4096] tensor took 14.6 us where 128 take 11.)
+    const int64_t want = ceil_div(n, static_cast<int64_t>(kBlock) * 16);
     return static_cast<int>(want < 1 ? 1 : want > kMaxParts ? kMaxParts : want);
 }
 
@@ -458,4 +483,63 @@ extern "C" int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes
     }
 #undef MIQ_FRAMED
     return check_launch("quantize_framed_kernel");
+}
+
+// Statistics + parameters (+ epilogue vectors) and the quantization (optionally into a zero-point frame): the two launches
+// of the dynamic activation quantizer behind one call.
+extern "C" int miq_dynamic_quantize_i8(const void* x, int x_dtype, int64_t planes, int64_t H, int64_t W, int64_t pad_top,
+                                       int64_t pad_bottom, int64_t pad_left, int64_t pad_right, const float* w_scale,
+                                       const float* bias, const float* w_rowsum, int64_t channels, float* scale_zp, float* alpha,
+                                       float* corr, int8_t* q, void* workspace, size_t workspace_bytes, unsigned* counter,
+                                       void* stream) {
+    MIQ_REQUIRE(planes >= 0 && H >= 0 && W >= 0, MIQ_EINVAL, "miq_dynamic_quantize_i8: negative size");
+    if (int rc = miq_dynamic_quant_params_i8(x, x_dtype, planes * H * W, w_scale, bias, w_rowsum, channels, scale_zp, alpha, corr,
+                                             workspace, workspace_bytes, counter, stream))
+        return rc;
+    return miq_quantize_tensor_i8(x, x_dtype, planes, H, W, pad_top, pad_bottom, pad_left, pad_right, scale_zp, q, stream);
+}
+
+// ---- a weight-only Linear on a dynamically quantized activation, as one call ---------------------------------------
+namespace {
+struct DynLayout {
+    size_t vectors, parts, xq, gemm, total;   // byte offsets of the pieces in the workspace; total size
+};
+DynLayout dyn_layout(int64_t M, int64_t N, int64_t K) {
+    DynLayout L{};
+    size_t at = 256;                                                                 // [scale, zero point, its int32 bits]
+    L.vectors = at; at += static_cast<size_t>(round_up(2 * N * 4, 256));             // alpha[N], corr[N]
+    L.parts = at;   at += static_cast<size_t>(round_up(miq_dynamic_quant_workspace(M * K), 256));
+    L.xq = at;      at += static_cast<size_t>(round_up(M * K, 256));                 // the quantized activation
+    L.gemm = at;    at += miq_gemm_i8_workspace(MIQ_W_NK, M, N, K);
+    L.total = at;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t miq_linear_dynamic_w8a8_workspace(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return dyn_layout(M, N, K).total;
+}
+
+extern "C" int miq_linear_dynamic_w8a8(const void* x, int x_dtype, const int8_t* W, int64_t M, int64_t N, int64_t K,
+                                       const float* w_scale, const float* bias, const float* w_rowsum, void* out, int out_dtype,
+                                       void* workspace, size_t workspace_bytes, unsigned* counter, void* stream) {
+    MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "miq_linear_dynamic_w8a8: negative size");
+    if (M == 0 || N == 0) return MIQ_OK;
+    MIQ_REQUIRE(K > 0, MIQ_EINVAL, "miq_linear_dynamic_w8a8: K must be positive (the activation's statistics need elements)");
+    MIQ_REQUIRE(M * K < (1ll << 31), MIQ_ERANGE, "miq_linear_dynamic_w8a8: M * K must stay below 2^31");
+    const DynLayout L = dyn_layout(M, N, K);
+    MIQ_REQUIRE(workspace && workspace_bytes >= L.total, MIQ_EWORKSPACE,
+                "miq_linear_dynamic_w8a8: needs %zu bytes of workspace (got %zu)", L.total, workspace_bytes);
+    MIQ_REQUIRE(aligned(workspace, 256), MIQ_EALIGN, "miq_linear_dynamic_w8a8: workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    float* scale_zp = reinterpret_cast<float*>(ws);
+    float* alpha = reinterpret_cast<float*>(ws + L.vectors);
+    float* corr = alpha + N;
+    int8_t* xq = reinterpret_cast<int8_t*>(ws + L.xq);
+    if (int rc = miq_dynamic_quant_params_i8(x, x_dtype, M * K, w_scale, bias, w_rowsum, N, scale_zp, alpha, corr, ws + L.parts,
+                                             L.xq - L.parts, counter, stream))
+        return rc;
+    if (int rc = miq_quantize_tensor_i8(x, x_dtype, 1, 1, M * K, 0, 0, 0, 0, scale_zp, xq, stream)) return rc;
+    return miq_gemm_i8(xq, W, MIQ_W_NK, M, N, K, corr, alpha, 0.0f, out, out_dtype, ws + L.gemm, L.total - L.gemm, stream);
 }
