@@ -580,6 +580,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     const int mbase = m0 + wm * WM + (lane >> 4) * 4;
     const int nbase = n0 + wn * WN + (lane & 15);
     const bool vec_ok = (g.HoWo & 3) == 0;
+    if constexpr (STREAM && BM == 256 && OUT != kOutBF16) {
+        // Streamed outputs leave through LDS, one channel's 256 pixels (1 KiB) per store instruction: a nontemporal
+        // store that covers only half a cache line per channel (the accumulator as it lies: 16 channels x 64 bytes) is
+        // written out as partial lines, and 822 MB of them take 250 us against 157 us for whole lines
+        // (tools/nchw_write_probe.hip).  Sixteen channels per channel-wave at a time: rows of 256 + 4 values keep both the
+        // 16-byte writes (sixteen rows at once) and the row-wise reads off each other's banks.
+        if (vec_ok) {
+            constexpr int kRowBytes = (BM + 4) * 4;
+            constexpr int kPassRows = WAVES_N * 16;
+            static_assert(kPassRows * kRowBytes <= 2 * STAGE && kPassRows % NWAVES == 0, "LDS of the transposed epilogue");
+            const int ms = m0 + lane * 4;
+            const bool row_ok = ms < g.M;
+            size_t obase = 0;
+            if (row_ok) obase = static_cast<size_t>(ms / g.HoWo) * g.Cout * g.HoWo + ms % g.HoWo;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = nbase + j * 16;
+                float al = 1.f, bi = 0.f;
+                if constexpr (OUT != kOutI32) {
+                    if (n < g.Cout) {
+                        al = g.alpha[n];
+                        if (g.bias) bi = g.bias[n];
+                    }
+                }
+                char* wr = smem + (wn * 16 + (lane & 15)) * kRowBytes + (wm * WM + (lane >> 4) * 4) * 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    v4i a = acc[i][j];
+                    if constexpr (OUT == kOutF32)
+                        a = v4i{__float_as_int(dequant1(a[0], bi, al, g.beta)), __float_as_int(dequant1(a[1], bi, al, g.beta)),
+                                __float_as_int(dequant1(a[2], bi, al, g.beta)), __float_as_int(dequant1(a[3], bi, al, g.beta))};
+                    *reinterpret_cast<v4i*>(wr + i * 64) = a;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = wave; r < kPassRows; r += NWAVES) {
+                    const int nn = n0 + (r >> 4) * WN + j * 16 + (r & 15);
+                    const v4i v = *reinterpret_cast<const v4i*>(smem + r * kRowBytes + lane * 16);
+                    if (row_ok && nn < g.Cout)
+                        __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(static_cast<int*>(g.out) + obase + static_cast<size_t>(nn) * g.HoWo));
+                }
+                if (j + 1 < FN) __syncthreads();
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = nbase + j * 16;
@@ -1844,6 +1890,12 @@ struct PackedWeight {
     int64_t total;
 };
 
+// Developer A/B switch over the output-store policy: MIQ_CONV_STREAM=0 cached, =1 nontemporal, unset: the caller's choice.
+static bool stream_choice(bool chosen) {
+    if (const char* f = dev_switch("MIQ_CONV_STREAM")) return f[0] == '1';
+    return chosen;
+}
+
 static PackedWeight packed_weight_layout(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     PackedWeight pw{};
     const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
@@ -1938,7 +1990,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
                 pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
             MIQ_REQUIRE(B * tiles_img * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
             set_patch_units(pa, B, HoWo, G.Hp, G.Wp, 1);
-            const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
+            const bool stream_out = stream_choice(G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16);
             switch (out_dtype) {
                 case MIQ_F32: return launch_planar<kOutF32, false, true>(pa, stream_out, st);
                 case MIQ_BF16: return launch_planar<kOutBF16, false, true>(pa, stream_out, st);
@@ -2024,7 +2076,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
         MIQ_REQUIRE(B * miq::ceil_div(G.Ho * G.Wo, kTM) * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");
         set_patch_units(pa, B, G.Ho * G.Wo, G.Hp, G.pitch, G.group);
         // as below: outputs far beyond the Infinity Cache stream past it (16-byte stores only)
-        const bool stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16;
+        const bool stream_out = stream_choice(G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && out_dtype != MIQ_BF16);
         switch (out_dtype) {
             case MIQ_F32:
                 return launch_planar<kOutF32>(pa, stream_out, st);
@@ -2060,7 +2112,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
     // which the Infinity Cache absorbs.
     a.wide16 = out_dtype == MIQ_BF16 && a.HoWo % 8 == 0 && miq::aligned(out, 16);
     // (8-byte nontemporal stores are slower than cached ones: bf16 outputs stream only as 16-byte vectors.)
-    a.stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16);
+    a.stream_out = stream_choice(G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16));
     switch (out_dtype) {
         case MIQ_F32:
             return launch<kOutF32>(a, st);
@@ -2216,7 +2268,7 @@ int conv2d_i8_dense(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, in
     a.xp_bytes = static_cast<uint32_t>(G.xp_bytes - origin);
     a.wp_bytes = static_cast<uint32_t>(G.wp_bytes);
     a.wide16 = out_dtype == MIQ_BF16 && a.HoWo % 8 == 0 && aligned(out, 16);
-    a.stream_out = G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16);
+    a.stream_out = stream_choice(G.M * Cout * static_cast<int64_t>(esz) >= (192ll << 20) && (out_dtype != MIQ_BF16 || a.wide16));
     switch (out_dtype) {
         case MIQ_F32: return launch<kOutF32>(a, st);
         case MIQ_BF16: return launch<kOutBF16>(a, st);
