@@ -1734,6 +1734,8 @@ __global__ __launch_bounds__(512, 2) void conv_stem_w8_kernel(StemW8Args g) {
             // groups that start inside Cout, if the wave's row is inside the image
             const int fx = min(4, max(0, (g.Wo - cur.x0 + 15) >> 4)), fc = min(4, max(0, (g.Cout - tn * 64 + 15) >> 4));
             stores = cur.y0 + wave < g.Ho ? fx * fc : 0;
+            // (fp32: instructions of four channels x the row's 64 pixels, those whose first channel is inside Cout)
+            if constexpr (OUT == kOutF32) stores = cur.y0 + wave < g.Ho ? min(16, max(0, (g.Cout - tn * 64 + 3) >> 2)) : 0;
         }
         const uint32_t nunit = unit + gridDim.x;
         const Block nxt = decode(nunit < units ? nunit : unit);
@@ -1760,7 +1762,37 @@ __global__ __launch_bounds__(512, 2) void conv_stem_w8_kernel(StemW8Args g) {
 
         // D[R][c] of fragment (i, f): R = 4*(lane>>4) + reg -> pixel i*16 + R of the wave's row, c = lane&15 -> channel f*16 + c
         const int y = cur.y0 + wave;
-        if (y < g.Ho) {
+        if constexpr (OUT == kOutF32) {
+            // fp32 outputs are streamed past the caches, and a nontemporal store that covers half a cache line per channel
+            // (the accumulator as it lies: sixteen channels x 64 bytes) is written out as partial lines at 3.2 TB/s against
+            // 5.3 TB/s for whole lines (tools/nchw_write_probe.hip).  So a wave turns its row, sixteen channels at a time,
+            // through an area of its own inside the patch every wave has just finished with, and stores four channels x
+            // the row's 64 pixels (256 bytes each) per instruction.
+            constexpr int kTrPitch = 272;   // one channel's 64 pixels + 16 bytes: the sixteen lanes of a 16-byte write meet 64 banks
+            static_assert(8 * 16 * kTrPitch <= kStemW8PatchBytes, "transposition areas inside one patch buffer");
+            __syncthreads();
+            if (y < g.Ho) {
+                char* const tr = smem + buf * kStemW8PatchBytes + wave * (16 * kTrPitch);
+                const int xs = cur.x0 + r * 4;   // this lane's four pixels when storing
+                float* const orow = static_cast<float*>(g.out) + static_cast<size_t>(cur.b) * g.Cout * HoWo + static_cast<size_t>(y) * g.Wo + xs;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const v4f a = acc[i][f];
+                        *reinterpret_cast<v4f*>(tr + r * kTrPitch + (i * 16 + q * 4) * 4) =
+                            v4f{dequant1f(a[0], bi[f], al[f], g.beta), dequant1f(a[1], bi[f], al[f], g.beta),
+                                dequant1f(a[2], bi[f], al[f], g.beta), dequant1f(a[3], bi[f], al[f], g.beta)};
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = tn * 64 + f * 16 + k * 4 + q;
+                        const v4f v = *reinterpret_cast<const v4f*>(tr + (k * 4 + q) * kTrPitch + r * 16);
+                        if (n < g.Cout && xs < g.Wo) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(orow + static_cast<size_t>(n) * HoWo));
+                    }
+                }
+            }
+        } else if (y < g.Ho) {
             const int xq = cur.x0 + q * 4;   // this lane's first pixel of fragment 0
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
