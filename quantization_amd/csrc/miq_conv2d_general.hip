@@ -39,6 +39,9 @@ struct GeneralArgs {
     int cblocks;         // channel blocks per group
     int Ho, Wo;
     int R;               // reduction length of one output: cin_g * KH * KW
+    // Grid folding of conv_general_kernel: grid.y and grid.z hold at most 65535 entries each, so channel blocks and images
+    // beyond that ride on grid.x, which is gx * fold_y * fold_z wide (x fastest).
+    int gx, gy, fold_y, fold_z;
 };
 
 constexpr int kRT = 128;   // reduction elements staged per round
@@ -67,7 +70,12 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pw = wave % PW, cw = wave / PW;
-    const int grp = blockIdx.y / g.cblocks, cb = blockIdx.y - grp * g.cblocks;
+    // (block indices unfolded: see GeneralArgs)
+    const int bx = static_cast<int>(blockIdx.x % static_cast<uint32_t>(g.gx)), fold = static_cast<int>(blockIdx.x / static_cast<uint32_t>(g.gx));
+    const int by = (fold % g.fold_y) * static_cast<int>(gridDim.y) + static_cast<int>(blockIdx.y);
+    const int bz = (fold / g.fold_y) * static_cast<int>(gridDim.z) + static_cast<int>(blockIdx.z);
+    if (by >= g.gy || bz >= g.B) return;   // (a whole workgroup: before any barrier)
+    const int grp = by / g.cblocks, cb = by - grp * g.cblocks;
     const int co_wg = cb * kCB;   // the workgroup's first channel inside its group
     // Thin layers (PW == 4) deal the output pixels of the whole batch over the lanes, image after image: a small image alone
     // would not fill a workgroup, and all images share the channel block's weights.  Otherwise blockIdx.z is the image.
@@ -77,20 +85,20 @@ __global__ __launch_bounds__(256) void conv_general_kernel(GeneralArgs g) {
     bool live[NPB];
 #pragma unroll
     for (int q = 0; q < NPB; ++q) {
-        p[q] = ((blockIdx.x * PW + pw) * NPB + q) * 64 + lane;
+        p[q] = ((bx * PW + pw) * NPB + q) * 64 + lane;
         if constexpr (kFlat) {
             live[q] = p[q] < g.B * HoWo;   // (B * HoWo and B * Cin * H * W fit 31 bits: checked by the host)
             img[q] = p[q] / HoWo;
             p[q] -= img[q] * HoWo;
         } else {
             live[q] = p[q] < HoWo;
-            img[q] = blockIdx.z;
+            img[q] = bz;
         }
         const int ho = p[q] / g.Wo, wo = p[q] - ho * g.Wo;
         ih0[q] = ho * g.sh - g.pt;
         iw0[q] = wo * g.sw - g.pl;
     }
-    const T* xg = static_cast<const T*>(g.x) + (static_cast<int64_t>(kFlat ? 0 : blockIdx.z) * g.Cin + grp * g.cin_g) * g.H * g.W;
+    const T* xg = static_cast<const T*>(g.x) + (static_cast<int64_t>(kFlat ? 0 : bz) * g.Cin + grp * g.cin_g) * g.H * g.W;
     const int img_elems = g.Cin * g.H * g.W;
     const int8_t* wg = g.w + static_cast<int64_t>(grp * g.cout_g + co_wg) * g.R;
     const int khw = g.KH * g.KW;
@@ -322,9 +330,14 @@ int launch_general(const GeneralArgs& a0, int64_t B, int64_t groups, hipStream_t
     // ... and four pixels a lane once that still leaves every CU a few workgroups
     const bool many = thin && ceil_div(B * HoWo, 1024) * gy >= 1024;
     const int64_t gx = thin ? ceil_div(B * HoWo, many ? 1024 : 256) : ceil_div(HoWo, 64);
-    MIQ_REQUIRE(gx < (1ll << 31) && gy <= 65535 && B <= 65535, MIQ_ERANGE,
-                "miq_conv2d_general: more than 65535 images or channel blocks (B=%lld, blocks=%lld)", (long long)B, (long long)gy);
-    const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(thin ? 1 : B));
+    const int64_t gz = thin ? 1 : B;
+    const int64_t fold_y = ceil_div(gy, 65535), fold_z = ceil_div(gz, 65535);
+    MIQ_REQUIRE(gx * fold_y * fold_z < (1ll << 31) && gy < (1ll << 31), MIQ_ERANGE,
+                "miq_conv2d_general: too many workgroups (pixels blocks=%lld, channel blocks=%lld, images=%lld)", (long long)gx,
+                (long long)gy, (long long)gz);
+    a.gx = static_cast<int>(gx); a.gy = static_cast<int>(gy); a.fold_y = static_cast<int>(fold_y); a.fold_z = static_cast<int>(fold_z);
+    const dim3 grid(static_cast<unsigned>(gx * fold_y * fold_z), static_cast<unsigned>(ceil_div(gy, fold_y)),
+                    static_cast<unsigned>(ceil_div(gz, fold_z)));
     if (cb == 1 && many)
         conv_general_kernel<T, OUT, 4, 1, 4><<<grid, 256, 0, st>>>(a);
     else if (cb == 1)

@@ -66,6 +66,8 @@ CASES = [
     (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
     (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
     (8, 256, 14, 14, 256, (3, 3), 1, 2, 2, 1),
+    # more channel blocks / images than a grid axis holds (65535): the excess rides on the grid's first axis
+    (1, 70000, 2, 2, 70000, (2, 2), 1, 1, 1, 70000), (66000, 16, 2, 2, 16, (2, 2), 1, 1, 1, 1),
 ]
 
 
