@@ -102,10 +102,10 @@ def kernel_source_sha():
 
 
 def profiled_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_traffic.json,
-    written by tools/pmc_traffic.sh), or None when that file was measured on other kernel sources than these."""
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r3_traffic.json,
+    written by tools/profile_round.sh), or None when that file was measured on other kernel sources than these."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as f:
             d = json.load(f)
         if d.get("source_sha") != kernel_source_sha() and kernel.startswith("gemm"):
             return None
@@ -782,8 +782,9 @@ def main():
         # the long tables go to a file; stdout carries the one short record, last
         out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
         try:
-            with open(os.path.join(out_dir, "bench_extra.json"), "w") as f:
-                json.dump({"headline": line, "extra": extra}, f, indent=1)
+            if world == 1 and not args.no_extras:   # (a run without the tables leaves the last full record alone)
+                with open(os.path.join(out_dir, "bench_extra.json"), "w") as f:
+                    json.dump({"headline": line, "extra": extra}, f, indent=1)
         except OSError as e:
             print(f"[bench] bench_extra.json not written: {e}", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The measurements the committed files under profiles/ come from, in one GPU call:
 #   tools/profile_round.sh OUTDIR
-#   1. bench.py (default flags)                         -> OUTDIR/bench.json
+#   1. bench.py (default flags)                         -> OUTDIR/bench.json, OUTDIR/bench_extra.json (the long tables)
 #   2. rocprofv3 --kernel-trace --stats over bench.py   -> OUTDIR/stats/*kernel_stats.csv (headline step), OUTDIR/stats_extras/ (with the extras)
 #   3. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE     -> OUTDIR/fetch, OUTDIR/write (separate runs)
 #   4. tools/kbench.py                                  -> OUTDIR/kbench.txt
@@ -12,6 +12,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 timeout -k 10 600 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
 tail -1 "$out/bench.json"
+cp gpurun_out/bench_extra.json "$out/bench_extra.json" 2>/dev/null
 # (the headline step alone, so that the GEMM kernel's average duration in the summary is that of the 8192^3 launch; then once with the extras)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-extras > "$out/stats.log" 2>&1 || { echo "stats failed"; tail -5 "$out/stats.log"; exit 1; }
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_extras" -o bench -- python3 bench.py --no-cpu-baseline --steps 20 > "$out/stats_extras.log" 2>&1 || { echo "stats (extras) failed"; tail -5 "$out/stats_extras.log"; exit 1; }
