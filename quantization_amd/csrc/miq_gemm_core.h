@@ -294,6 +294,51 @@ __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2]
                 continue;
             }
         }
+        if constexpr ((OUT == kOutF32 || OUT == kOutI32) && NT) {
+            // Whole cache lines per store instruction.  As the accumulators lie, an instruction writes sixteen rows x 64
+            // bytes, and a nontemporal store of half a line is written out as a partial line (3.2 TB/s against 5.3 TB/s for
+            // whole lines, tools/nchw_write_probe.hip).  The two 16-column fragments of a row trade halves between lanes r
+            // and r ^ 8 of each 16-lane row (one DPP rotation): an instruction then writes eight rows x 128 bytes.
+            if (vec_ok && nb + 32 <= g.N) {   // wave-uniform
+                const int r = lane & 15;
+                const bool lo = r < 8;
+                const int n = nb + (lo ? 0 : 16) + (lane >> 4) * 4;
+#pragma unroll
+                for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int mb = m0 + qm * 128 + wm * 64 + i * 16;
+                        const int m = mb + r, mc = m < g.M ? m : g.M - 1;   // (rows past the edge compute and trade, and store nothing)
+                        int y[2][4];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const V4 a = acc[qm][qn][i][j];
+                            if constexpr (OUT == kOutI32) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[j][e] = a[e];
+                            } else {
+                                float a4[4], b4[4];
+                                row_params(mc, a4, b4, j);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[j][e] = __float_as_int(dequant1(a[e], b4[e], a4[e], g.beta));
+                            }
+                        }
+                        v4i first, second;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int send = lo ? y[1][e] : y[0][e];
+                            const int recv = __builtin_amdgcn_update_dpp(0, send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                            first[e] = lo ? y[0][e] : recv;
+                            second[e] = lo ? recv : y[1][e];
+                        }
+                        const int m1 = mb + (r & 7), m2 = m1 + 8;
+                        int* o1 = static_cast<int*>(g.out) + static_cast<size_t>(m1) * g.ldc + n;
+                        if (m1 < g.M) __builtin_nontemporal_store(first, reinterpret_cast<v4i*>(o1));
+                        if (m2 < g.M) __builtin_nontemporal_store(second, reinterpret_cast<v4i*>(o1 + static_cast<size_t>(8) * g.ldc));
+                    }
+                continue;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = nb + j * 16 + (lane >> 4) * 4;
