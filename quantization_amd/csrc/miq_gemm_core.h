@@ -221,15 +221,85 @@ __device__ __forceinline__ float dequant1(float acc, float bias, float alpha, fl
 // EXT (the int8 GEMM's argument block): g.by_row != 0 takes bias / alpha per output ROW m instead of per column n (the
 // transposed product of a column-sharded layer, whose rows are the output channels); OUT == kOutI8 requantises the
 // dequantised value, clamp(rint(y / g.out_div)), four consecutive columns as one dword.
-template <int OUT, bool NT = true, bool WIDE16 = true, int QN = 2, bool EXT = false, typename Args, typename V4>
+//
+// ADJ (QN == 2): the kernel staged the column operand so that a wave's two quadrants are NEIGHBOURS in the output, columns
+// wn * 64 + qn * 32 .. + 32 of the tile instead of qn * 128 + wn * 32 .. + 32: a row of a wave is then 64 consecutive columns,
+// 128 bytes at bf16, and the bf16 epilogue stores whole cache lines as the fp32 one does.
+template <int OUT, bool NT = true, bool WIDE16 = true, int QN = 2, bool EXT = false, bool ADJ = false, typename Args, typename V4>
 __device__ __forceinline__ void store_tile_256(const Args& g, const V4 (&acc)[2][QN][4][2], int m0, int n0, int wm,
                                                int wn, int lane) {
+    static_assert(!ADJ || QN == 2, "neighbouring quadrants: two of them");
     const bool vec_ok = (g.ldc & 3) == 0;
     bool by_row = false;
     if constexpr (EXT) by_row = g.by_row != 0;
+    if constexpr (ADJ && OUT == kOutBF16 && WIDE16 && NT) {
+        const int nb0 = n0 + wn * 64;
+        if ((g.ldc & 7) == 0 && nb0 + 64 <= g.N) {   // wave-uniform
+            // Per quadrant as below (the fragments j = 0, 1 trade 16-lane rows: eight consecutive columns a lane); then
+            // the two quadrants trade halves between lanes r and r ^ 8 of every 16-lane row (one DPP rotation), so that a
+            // store instruction writes eight rows x 128 bytes instead of sixteen rows x 64: a nontemporal store of half a
+            // cache line is written out as a partial line (tools/nchw_write_probe.hip).
+            float al[2][2][4], bi[2][2][4];
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nb0 + qn * 32 + j * 16 + (lane >> 4) * 4 + e;
+                        al[qn][j][e] = by_row ? 1.f : g.alpha[n];
+                        bi[qn][j][e] = (by_row || !g.bias) ? 0.f : g.bias[n];
+                    }
+            const int r = lane & 15;
+            const bool lo = r < 8;
+            const int n = nb0 + (lo ? 0 : 32) + paired_offset(lane);
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mb = m0 + qm * 128 + wm * 64 + i * 16;
+                    const int m = mb + r, mc = m < g.M ? m : g.M - 1;   // (rows past the edge compute and trade, and store nothing)
+                    float ra = 1.f, rb = 0.f;
+                    if constexpr (EXT) {
+                        if (by_row) {
+                            ra = g.alpha[mc];
+                            rb = g.bias ? g.bias[mc] : 0.f;
+                        }
+                    }
+                    v4i v[2];
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn) {
+                        uint2 p[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const V4 a = acc[qm][qn][i][j];
+                            float y[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                y[e] = by_row ? dequant1(a[e], rb, ra, g.beta) : dequant1(a[e], bi[qn][j][e], al[qn][j][e], g.beta);
+                            p[j] = pack4_bf16(y[0], y[1], y[2], y[3]);
+                        }
+                        v[qn] = pair_rows_bf16(p[0], p[1]);
+                    }
+                    v4i first, second;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int send = lo ? v[1][e] : v[0][e];
+                        const int recv = __builtin_amdgcn_update_dpp(0, send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                        first[e] = lo ? v[0][e] : recv;
+                        second[e] = lo ? recv : v[1][e];
+                    }
+                    const int m1 = mb + (r & 7), m2 = m1 + 8;
+                    uint16_t* o1 = static_cast<uint16_t*>(g.out) + static_cast<size_t>(m1) * g.ldc + n;
+                    if (m1 < g.M) __builtin_nontemporal_store(first, reinterpret_cast<v4i*>(o1));
+                    if (m2 < g.M) __builtin_nontemporal_store(second, reinterpret_cast<v4i*>(o1 + static_cast<size_t>(8) * g.ldc));
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int qn = 0; qn < QN; ++qn) {
-        const int nb = n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
+        const int nb = ADJ ? n0 + wn * 64 + qn * 32 : n0 + qn * 128 + wn * 32;   // first of this wave's 32 channels in the quadrant
         float al[2][4], bi[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

@@ -335,7 +335,11 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int ra_ = m0 + h * 128 + srow + i * 64, rw_ = n0 + h * 128 + srow + i * 64;
+            // Activation rows as they come; the column operand permuted so that the 32 rows wave column wn reads from
+            // half-tile h are output columns wn * 64 + h * 32 .. + 32: a wave's two quadrants are neighbours in the output
+            // (store_tile_256, ADJ) and its rows leave as whole cache lines whatever the output type.
+            const int rho = srow + i * 64;
+            const int ra_ = m0 + h * 128 + rho, rw_ = n0 + (rho >> 5) * 64 + h * 32 + (rho & 31);
             abase[h][i] = ra_ < g.M ? static_cast<uint32_t>(ra_) * g.K + cbyte : kOob;
             wbase[h][i] = rw_ < g.N ? static_cast<uint32_t>(rw_) * g.K + cbyte : kOob;
         }
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(512) void gemm_i8_256_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued for tiles past K
 
-    store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0, 2, true>(g, acc, m0, n0, wm, wn, lane);
+    store_tile_256<OUT, (ABL & 256) == 0, (ABL & 512) == 0, 2, true, true>(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------
