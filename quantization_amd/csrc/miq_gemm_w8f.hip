@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
     constexpr int kWst = 9 * NQ * 64 * kChunk;           // bytes of one weight stage (bf16)
     constexpr int kWInstr = kWst / 1024;                 // wave-instructions that fetch it (36 or 18)
     constexpr int kPatch = kPatchW8Bytes;
+    constexpr bool kPiecesFirst = STREAM && NP == 2;   // order of a stage's fetch pieces and output rows: see the taps
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2] patches, [2] weight stages
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1429,7 +1430,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
                 };
                 auto tap = [&](auto T) {
                     constexpr int t = decltype(T)::value, s = t & 1;
-                    if constexpr (t < 6) {
+                    // Large fp32 outputs of fp32 activations (STREAM, four stages a unit): the next stage's six pieces go out
+                    // beside taps 0-2 and the finished unit's rows beside taps 2-8, every row behind the last piece.  Vector
+                    // memory operations retire in order, so a row stored before a piece has to be written out to HBM before
+                    // that piece counts as landed at the next stage's start (64->64 56x56 at batch 256: 240 -> 217 us whole
+                    // call; with one plane, or outputs the caches absorb, the bunched pieces cost 1-5 % instead).
+                    if constexpr (kPiecesFirst) {
+                        if constexpr (t < 3) {
+                            if (fetch) {
+                                const bool a = issue_piece(nxt, ncg, buf ^ 1, !w_res, 2 * t), b = issue_piece(nxt, ncg, buf ^ 1, !w_res, 2 * t + 1);
+                                if (a || b) stores = 0;
+                            }
+                        }
+                    } else if constexpr (t < 6) {
                         if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_res, t)) stores = 0;
                     }
                     if constexpr (t + 1 < 9) read_tap(std::integral_constant<int, (t + 1) & 1>{}, (t + 1) / 3, (t + 1) % 3);
@@ -1440,7 +1453,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
                             acc[i][j] = mfma_w8<F16>(af[s][i], wf[s][j], acc[i][j]);
                     // the finished unit's row t leaves behind this tap's MFMAs, as a block of its own behind a branch
                     __builtin_amdgcn_sched_barrier(0);
-                    if (flush) stores += store_step(rout, prev, T);
+                    if constexpr (kPiecesFirst) {
+                        if constexpr (t >= 2) {
+                            if (flush) stores += store_step(rout, prev, std::integral_constant<int, t - 2>{});
+                        }
+                    } else {
+                        if (flush) stores += store_step(rout, prev, T);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 read_tap(std::integral_constant<int, 0>{}, 0, 0);
