@@ -1139,7 +1139,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
-    const bool w_once = g.ncg == 1;   // every stage of this workgroup multiplies by the same weights
+    // A workgroup keeps one channel tile, so with at most two input-channel groups its filters stay where the first unit
+    // put them (group cg in weight stage cg: the two stages are then not a double buffer) and later stages fetch patches only.
+    const bool w_res = g.ncg <= 2;
 
     struct Unit {
         uint32_t b, p0, y0, tn;
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
             any = true;
         }
         if (weights && q < 36) {
-            dma16(rw, smem + 2 * kPatch + (w_once ? 0 : buf) * kWStageBytes + q * 1024,
+            dma16(rw, smem + 2 * kPatch + (w_res ? cg : buf) * kWStageBytes + q * 1024,
                   ((u.tn * g.ncg + cg) * 36 + q) * 1024 + lane * kChunk);
             any = true;
         }
@@ -1408,6 +1410,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     }
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) (void)issue_piece(cur, 0, 0, true, k);
+    if (w_res && g.ncg == 2) {   // the second group's filters, for good
+#pragma unroll 1
+        for (int q = wave; q < 36; q += 8)
+            dma16(rw, smem + 2 * kPatch + kWStageBytes + q * 1024, ((cur.tn * 2 + 1) * 36 + q) * 1024 + lane * kChunk);
+    }
     if constexpr (DIRECT) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -1457,7 +1464,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
             MIQ_PLANAR_STAMP(3)
             const bool flush = pending && cg == 0;
             const char* patch = smem + buf * kPatch;
-            const char* wst = smem + 2 * kPatch + (w_once ? 0 : buf) * kWStageBytes + w_lane;
+            const char* wst = smem + 2 * kPatch + (w_res ? cg : buf) * kWStageBytes + w_lane;
             {
                 v4i af[2][FM], wf[2][FN];   // the fragments of tap t + 1 are read while the MFMAs of tap t run
                 auto read_tap = [&](auto S, int kh, int kw) {
@@ -1485,7 +1492,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                         }
                     }
                     if constexpr (t < 6) {
-                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_once, t)) {
+                        if (fetch && issue_piece(nxt, ncg, buf ^ 1, !w_res, t)) {
                             stores = 0;
                             if constexpr (DIRECT) after_patch += 1;
                         }
