@@ -1393,6 +1393,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
 #endif
     int unit = blockIdx.x;
     Unit cur = decode(unit);
+    // The stage after a given one, decoded ahead of time: its divisions run among the taps of the stage before (behind the
+    // stage's barrier they cost every wave 360-600 cycles with no MFMA in flight).
+    struct Next {
+        int cg, unit;
+        bool fetch;
+        Unit u;
+    };
+    auto successor = [&](int of_unit, int of_cg) {
+        Next n;
+        n.cg = of_cg + 1;
+        n.unit = of_unit;
+        if (n.cg == g.ncg) {
+            n.cg = 0;
+            n.unit = of_unit + static_cast<int>(gridDim.x);
+        }
+        n.fetch = n.unit < g.units;
+        n.u = decode(n.fetch ? n.unit : of_unit);   // (past the last unit: arithmetic on a unit that exists, never used)
+        return n;
+    };
+    Next nx = successor(unit, 0);
+    Unit upcoming = cur;
     // DIRECT, before the loop: where piece p of this wave lands.  The LDS that is idle until the loop starts (the second
     // patch buffer, the second weight stage and the staging areas) holds 49 wave-pieces: the first stage's six pieces are
     // fetched at once and re-laid together.
@@ -1429,7 +1450,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     Unit prev{};
     __amdgpu_buffer_rsrc_t rout = image_of(cur);
     for (; unit < g.units; unit += gridDim.x) {
-        cur = decode(unit);
+        cur = upcoming;
         int aoff[FM];   // patch address of each fragment row this lane supplies: plane lane>>4, pixel (y - y0) * pitch + x
         {
             uint32_t qfirst = cur.p0 + wm * FM * 16 + (lane & 15);
@@ -1453,14 +1474,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
             MIQ_PLANAR_STAMP(1)
             __syncthreads();
             MIQ_PLANAR_STAMP(2)
-            // the next stage, fetched piece by piece among this stage's taps
-            int ncg = cg + 1, nunit = unit;
-            if (ncg == g.ncg) {
-                ncg = 0;
-                nunit = unit + gridDim.x;
-            }
-            const bool fetch = nunit < g.units;
-            const Unit nxt = decode(fetch ? nunit : unit);
+            // the next stage (decoded during the stage before), fetched piece by piece among this stage's taps
+            const Next cn = nx;
+            const int ncg = cn.cg;
+            const bool fetch = cn.fetch;
+            const Unit nxt = cn.u;
+            if (ncg == 0) upcoming = nxt;
             MIQ_PLANAR_STAMP(3)
             const bool flush = pending && cg == 0;
             const char* patch = smem + buf * kPatch;
@@ -1478,6 +1497,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
                 };
                 auto tap = [&](auto T) {
                     constexpr int t = decltype(T)::value, s = t & 1;
+                    if constexpr (t == 6) nx = successor(cn.unit, cn.cg);   // scalar work beside this tap's MFMAs
                     if constexpr (DIRECT && t >= 1 && t <= 6) {
                         if (fetch) {   // piece t - 1 has landed once only what was issued after it is left in flight
                             wait_vmcnt_upto16(after_patch);
