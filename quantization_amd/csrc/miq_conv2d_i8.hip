@@ -78,9 +78,18 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     g.ptot = B * g.Hp * g.pitch;
     const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
     g.planar = false;
-    if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && (g.Ho * g.Wo) % 4 == 0 && g.M >= 4 * kTM &&
-        !(sw && sw[0] == '0')) {
+    if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && g.M >= 4 * kTM && !(sw && sw[0] == '0')) {
+        // Images whose pixel count is no multiple of four (7 x 7) leave pixel by pixel; their rows then need no whole
+        // dwords of pixels either, and a tile holds more of them (eight 7 x 7 images instead of six).
+        if ((g.Ho * g.Wo) % 4 != 0) {
+            g.pitch = g.Wp;
+            g.ptot = B * g.Hp * g.pitch;
+        }
         g.planar = patch_tiling(g.Ho * g.Wo, g.Wo, g.Hp, g.pitch, kPlaneSlots, g.group);
+        if (!g.planar) {
+            g.pitch = round_up(g.Wp, 4);
+            g.ptot = B * g.Hp * g.pitch;
+        }
     }
     if (g.planar) {
         g.xp_bytes = g.ptot * Cin;
@@ -1068,6 +1077,7 @@ struct PlanarArgs {
     uint32_t wo_magic;            // floor(2^32 / Wo) + 1
     uint32_t xp_bytes, wp_bytes;
     int wide16;                   // bf16 output: paired 16-byte stores (HoWo % 8 == 0, 16-byte aligned output)
+    int ragged;                   // NCHW output with HoWo % 4 != 0 (7 x 7 images): a lane's four pixels are stored one by one
     // channels-last form (CL kernels): xp is the caller's [image][padded row][padded column][cin] activation and
     // out[b][y + border][x + border][channel] is addressed with these element strides
     int cin;
@@ -1127,9 +1137,14 @@ constexpr int kDirectStageBytes = 1792;   // 16 channels x cpc chunks of one wav
 // bytes into the patch (chunk planes with a border that is zeroed once: interior writes never touch it; rows outside the
 // image arrive as zeros from out-of-range DMA offsets).  A wave consumes only what it fetched itself, behind a counted
 // vmcnt that leaves the younger output stores in flight, so no barrier is added.
-template <int OUT, bool STREAM, bool CL, bool DIRECT = false>
+//
+// RAGGED = NCHW output whose images' pixel count is no multiple of four (7 x 7): a lane's four pixels are not one aligned
+// 16-byte run (they may even lie in two images of a small-image unit) and leave one by one.  A kernel of its own: as a
+// run-time branch of the others its code costs the bf16 form 40 spilled registers.
+template <int OUT, bool STREAM, bool CL, bool DIRECT = false, bool RAGGED = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
     static_assert(!(CL && DIRECT), "DIRECT stages an NCHW activation");
+    static_assert(!RAGGED || (!CL && !DIRECT && !STREAM && OUT != kOutI8), "RAGGED: NCHW outputs from the padded copy");
     constexpr int FM = 7, FN = 2;
     constexpr int kSlots = DIRECT ? kDirectSlots : kPlaneSlots;   // slots per chunk plane
     constexpr int kPatch = 4 * kSlots * kChunk;                   // bytes of one patch buffer
@@ -1310,6 +1325,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
         const uint32_t p = u.p0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4;   // HoWo % 4 == 0: four pixels in or out together
         const uint32_t im = __umulhi(p, g.hw_magic), pp = p - im * g.HoWo;   // image of the unit, pixel inside it
         const uint32_t at = im * g.Cout * g.HoWo + pp;
+        if constexpr (RAGGED) {
+            {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
+                    v4i a = done[i][j];
+                    asm volatile("" : "+v"(a));   // (opaque, as above)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t pe = p + e, ime = __umulhi(pe, g.hw_magic), ppe = pe - ime * g.HoWo;
+                        const uint32_t off = pe < static_cast<uint32_t>(g.pix_end) && n < g.Cout ? ((ime * g.Cout + n) * g.HoWo + ppe) * kEsz : kOob;
+                        if constexpr (OUT == kOutI32) {
+                            __builtin_amdgcn_raw_buffer_store_b32(a[e], r, off, 0, kNt);
+                        } else {
+                            const float y = dequant1(a[e], bi[j], al[j], g.beta);
+                            if constexpr (OUT == kOutF32)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(y), r, off, 0, kNt);
+                            else
+                                __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>(f32_to_bf16_bits(y)), r, off, 0, kNt);
+                        }
+                    }
+                }
+                return 4 * FN;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = u.tn * 64 + wn * 32 + j * 16 + (lane & 15);
@@ -1360,6 +1400,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PlanarArgs g) {
             return 0;
         } else if constexpr (CL) {
             return store_row_cl(r, u, T);
+        } else if constexpr (RAGGED) {
+            return store_row_nchw(r, u, T);
         } else if constexpr (OUT == kOutBF16) {
             if (g.wide16) {
                 if constexpr (t % 2 == 1)
@@ -1583,6 +1625,11 @@ int launch_planar(const PlanarArgs& g, bool stream_out, hipStream_t st) {
     void (*kern)(PlanarArgs) = conv3x3_patch_kernel<OUT, false, CL, DIRECT>;
     if constexpr (!CL) {
         if (stream_out) kern = conv3x3_patch_kernel<OUT, true, false, DIRECT>;
+    }
+    if constexpr (!CL && !DIRECT && OUT != kOutI8) {
+        if (g.ragged) kern = conv3x3_patch_kernel<OUT, false, false, false, true>;
+    } else {
+        if (g.ragged) return fail(MIQ_EINVAL, "conv3x3_patch_kernel: pixel-by-pixel stores exist for NCHW outputs from the padded copy only");
     }
     // all of a CU's LDS (DIRECT: smaller patch planes make room for the eight staging areas)
     constexpr int kLds = DIRECT ? 2 * 4 * kDirectSlots * kChunk + 2 * kWStageBytes + 8 * kDirectStageBytes : 2 * kPlanarStage;
@@ -2098,6 +2145,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
         pa.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(G.Wo)) + 1u;
         pa.xp_bytes = (uint32_t)G.xp_bytes; pa.wp_bytes = (uint32_t)G.wp_bytes;
         pa.wide16 = out_dtype == MIQ_BF16 && pa.HoWo % 8 == 0 && miq::aligned(out, 16);
+        pa.ragged = pa.HoWo % 4 != 0;
         if (const char* sp = dev_switch("MIQ_PLANAR_STAMPS"))   // address of a device buffer of 512 * 64 uint64
             pa.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0));
         MIQ_REQUIRE(B * miq::ceil_div(G.Ho * G.Wo, kTM) * pa.tiles_n < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8: too many tiles");

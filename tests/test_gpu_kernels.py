@@ -278,8 +278,11 @@ CONV_SHAPES = [
     (3, 64, 56, 56, 64, 3, 1, 1), (4, 128, 28, 28, 128, 3, 1, 1), (5, 64, 30, 28, 192, 3, 1, 1), (4, 64, 40, 40, 64, 3, 1, 0),
     # the patch kernel with several small images per tile (a last tile with one image; two channel groups and tiles)
     (11, 64, 14, 14, 64, 3, 1, 1), (12, 128, 14, 14, 192, 3, 1, 1),
-    # 3 x 3 / stride 1 on whole channel groups with a pixel count that is not a multiple of 4: stays on the im2col-order kernel
+    # 3 x 3 / stride 1 on whole channel groups with a pixel count that is not a multiple of 4: the patch kernel storing pixel
+    # by pixel (eight 7 x 7 images a tile, rows of Wp slots; four channel groups; one 21 x 21 image a tile; tiles of a
+    # 27 x 33 and a 45 x 45 image whose last pixel quads straddle the image's end)
     (40, 64, 7, 7, 70, 3, 1, 1), (37, 128, 7, 7, 64, 3, 1, 1), (40, 64, 9, 9, 64, 3, 1, 0), (4, 64, 27, 33, 16, 3, 1, 1),
+    (37, 256, 7, 7, 130, 3, 1, 1), (10, 64, 21, 21, 64, 3, 1, 1), (3, 64, 45, 45, 32, 3, 1, 1),
     # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
     (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
     (2, 3, 30, 224, 64, 7, 2, 3),    # two 64-pixel blocks a row, the second ragged
@@ -364,7 +367,7 @@ def test_conv_resnet_layer_vs_torch(N):
                                               # the LDS-resident-patch kernel
                                               (5, 64, 20, 20, 70, 3, 1, 1), (3, 128, 28, 28, 24, 3, 1, 1),
                                               (5, 64, 20, 21, 16, 3, 1, 1), (40, 64, 7, 7, 70, 3, 1, 1),
-                                              (4, 64, 27, 33, 16, 3, 1, 1),
+                                              (4, 64, 27, 33, 16, 3, 1, 1), (37, 128, 7, 7, 64, 3, 1, 1), (10, 64, 21, 21, 64, 3, 1, 1),
                                               # strided 1 x 1: the subsampling re-layout
                                               (2, 64, 16, 16, 70, 1, 2, 0), (2, 24, 9, 11, 12, 1, 2, 0),
                                               # stems: the row-block kernel (fp32) beside the im2col-order one (bf16)
