@@ -371,6 +371,8 @@ extern "C" size_t miq_conv2d_general_workspace(int x_dtype, int64_t B, int64_t C
                                                int64_t KW, int64_t stride_h, int64_t stride_w, int64_t pad_top, int64_t pad_bottom,
                                                int64_t pad_left, int64_t pad_right, int64_t dil_h, int64_t dil_w, int64_t groups) {
     if (groups != 1) return 0;
+    if (KH == 1) dil_h = 1;   // as in miq_conv2d_general: a filter one tap high / wide has no dilation
+    if (KW == 1) dil_w = 1;
     if (x_dtype == MIQ_I8)
         return miq::conv2d_i8_dense_workspace(B, Cin, H, W, Cout, KH, KW, stride_h, stride_w, pad_top, pad_bottom, pad_left,
                                               pad_right, dil_h, dil_w);
@@ -398,6 +400,11 @@ extern "C" int miq_conv2d_general(const void* x, int x_dtype, const int8_t* w, i
                 "miq_conv2d_general: unknown x_dtype %d", x_dtype);
     MIQ_REQUIRE(out_dtype == MIQ_F32 || out_dtype == MIQ_BF16 || (out_dtype == MIQ_I32 && x_dtype == MIQ_I8), MIQ_EINVAL,
                 "miq_conv2d_general: out_dtype must be MIQ_F32, MIQ_BF16 or, for int8 activations, MIQ_I32");
+    // A filter one tap high (wide) has no dilation along that axis, whatever the caller names: the dense kernels' "a tap is
+    // a row of its own" form of a dilation along x divides by the taps of a filter row with a 32-bit reciprocal, which one
+    // tap a row does not have.
+    if (KH == 1) dil_h = 1;
+    if (KW == 1) dil_w = 1;
     const int64_t eh = dil_h * (KH - 1) + 1, ew = dil_w * (KW - 1) + 1;   // extent of the dilated filter
     MIQ_REQUIRE(H + pad_top + pad_bottom >= eh && W + pad_left + pad_right >= ew, MIQ_EINVAL,
                 "miq_conv2d_general: dilated filter larger than the padded input");

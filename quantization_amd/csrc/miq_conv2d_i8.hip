@@ -2031,7 +2031,7 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
 
     // 3 x 3 / stride 1 layers whose rows are whole dwords: the patch kernel stages the NCHW activation itself (no padded
     // copy, no re-layout launch); only the filters are re-laid, into the workspace.
-    if (G.planar && G.group == 1 && W % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
+    if (G.planar && G.group == 1 && W % 4 == 0 && (G.Ho * G.Wo) % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
         !(dev_switch("MIQ_CONV_DIRECT") && dev_switch("MIQ_CONV_DIRECT")[0] == '0')) {
         const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
         int64_t rows = 0;

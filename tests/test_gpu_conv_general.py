@@ -66,6 +66,9 @@ CASES = [
     (4, 64, 28, 28, 64, (3, 3), 1, 2, 2, 1), (2, 128, 20, 20, 256, (3, 3), (2, 1), (1, 0), (1, 2), 1),
     (3, 32, 30, 30, 160, (3, 3), (1, 2), "valid", (2, 1), 1), (2, 70, 17, 19, 33, (2, 4), 1, "same", (3, 2), 1),
     (8, 256, 14, 14, 256, (3, 3), 1, 2, 2, 1),
+    # a dilation named along an axis on which the filter has one tap (it then has none): dense and grouped
+    (4, 39, 19, 39, 22, (2, 1), (2, 3), (2, 3), (1, 2), 1), (2, 20, 30, 31, 14, (4, 1), 3, 3, 2, 1),
+    (2, 16, 12, 12, 16, (1, 3), 1, 1, (3, 1), 1), (2, 8, 9, 9, 8, (3, 1), 1, 1, (1, 2), 8), (2, 8, 9, 9, 16, (1, 1), 2, 0, 3, 2),
     # more channel blocks / images than a grid axis holds (65535): the excess rides on the grid's first axis
     (1, 70000, 2, 2, 70000, (2, 2), 1, 1, 1, 70000), (66000, 16, 2, 2, 16, (2, 2), 1, 1, 1, 1),
 ]

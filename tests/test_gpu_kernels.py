@@ -283,6 +283,8 @@ CONV_SHAPES = [
     # 27 x 33 and a 45 x 45 image whose last pixel quads straddle the image's end)
     (40, 64, 7, 7, 70, 3, 1, 1), (37, 128, 7, 7, 64, 3, 1, 1), (40, 64, 9, 9, 64, 3, 1, 0), (4, 64, 27, 33, 16, 3, 1, 1),
     (37, 256, 7, 7, 130, 3, 1, 1), (10, 64, 21, 21, 64, 3, 1, 1), (3, 64, 45, 45, 32, 3, 1, 1),
+    # ... and rows of whole dwords whose padding leaves such a pixel count (not for the kernel that stages the NCHW activation)
+    (3, 64, 37, 20, 76, 3, 1, 2), (3, 64, 49, 28, 70, 3, 1, 0),
     # stems (Cin <= 4, 5-8 filter columns, stride 2): ragged tiles, ragged channel tiles, 8 x 8 filters
     (2, 3, 32, 32, 64, 7, 2, 3), (3, 3, 45, 40, 80, 7, 2, 3), (2, 2, 33, 48, 130, 5, 2, 2), (1, 4, 64, 64, 64, 8, 2, 3),
     (2, 3, 30, 224, 64, 7, 2, 3),    # two 64-pixel blocks a row, the second ragged
