@@ -309,8 +309,59 @@ def fuzz_quantizer(n):
             report("quantizer", str(dt), (rows, cols, mode))
 
 
+def fuzz_layers(n):
+    """Random nn.Linear / nn.Conv2d modules through the weight-only Quantizer (from_float + forward) on int8 and
+    floating-point activations: the stored weight against the oracle, the output against the float64 product of the
+    stored weight (Weight_Only/Quantizer.py:73-91: (x . Wq + b) * scale)."""
+    from quantization_amd.quant.Weight_Only import Quantizer
+    qp = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+    g = torch.Generator(device=dev).manual_seed(seed + 5)
+    for it in range(n):
+        torch.manual_seed(seed * 100003 + it)
+        has_bias = bool(rng.integers(0, 2))
+        if rng.integers(0, 2):
+            K, Nn = int(rng.integers(1, 600)), int(rng.integers(1, 400))
+            mod = torch.nn.Linear(K, Nn, bias=has_bias)
+            lead = tuple(int(v) for v in rng.integers(1, 6, size=int(rng.integers(1, 3))))
+            xshape, args, kw = lead + (K,), ("linear", K, Nn, lead, has_bias), None
+        else:
+            groups = int(pick([1, 1, 1, 2, 4]))
+            C, Co = groups * int(rng.integers(1, 40)), groups * int(rng.integers(1, 40))
+            ks = (int(rng.integers(1, 5)), int(rng.integers(1, 5))) if rng.integers(0, 3) == 0 else int(rng.integers(1, 5))
+            st = int(rng.integers(1, 3))
+            pd = pick([0, 1, 2, (1, 2), "same", "valid"])
+            dl = int(pick([1, 1, 2]))
+            if pd == "same" and st != 1:
+                st = 1
+            mod = torch.nn.Conv2d(C, Co, ks, stride=st, padding=pd, dilation=dl, groups=groups, bias=has_bias)
+            H, W = int(rng.integers(8, 30)), int(rng.integers(8, 30))
+            xshape, args = (int(rng.integers(1, 4)), C, H, W), ("conv", C, Co, ks, st, pd, dl, groups, H, W, has_bias)
+            kw = dict(stride=mod.stride, padding=mod.padding, dilation=mod.dilation, groups=groups)
+        mod = mod.to(dev)
+        ql = Quantizer.from_float(module=mod, data_metry=qp)
+        rq, rs, _ = O.quantize_channel_sym_int8(mod.weight.detach().cpu().numpy())
+        if not np.array_equal(ql.weight.cpu().numpy(), rq):
+            report("layers", "stored weight", args)
+            continue
+        wq, sc = ql.weight.double(), torch.from_numpy(rs.reshape(-1)).to(dev).double()
+        bd = mod.bias.detach().double() if has_bias else torch.zeros(wq.shape[0], device=dev, dtype=torch.float64)
+        for xdt in (torch.int8, pick([torch.float32, torch.float16, torch.bfloat16])):
+            x = ri8(xshape, g) if xdt == torch.int8 else torch.randn(xshape, device=dev, generator=g).to(xdt)
+            y = ql(x)
+            xd = x.double()
+            if kw is None:
+                ref, mag = (xd @ wq.t() + bd) * sc, (xd.abs() @ wq.abs().t() + bd.abs()) * sc
+            else:
+                v = (1, -1, 1, 1)
+                ref = (F.conv2d(xd, wq, **kw) + bd.view(v)) * sc.view(v)
+                mag = (F.conv2d(xd.abs(), wq.abs(), **kw) + bd.abs().view(v)) * sc.view(v)
+            if y.shape != ref.shape or not within(y, ref, mag, torch.float32):
+                report("layers", f"forward on {xdt}", args)
+                break
+
+
 FAMILIES = {"gemm": fuzz_gemm, "conv": fuzz_conv, "gemm_w8": fuzz_gemm_w8, "conv_w8": fuzz_conv_w8,
-            "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer}
+            "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer, "layers": fuzz_layers}
 
 
 def run(families, cases, s):
