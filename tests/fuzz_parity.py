@@ -360,8 +360,77 @@ def fuzz_layers(n):
                 break
 
 
+def fuzz_pool(n):
+    """miq_pool2d_to_i8 (QuantizedMaxPool2d / QuantizedAvgPool2d, quant/Weight_Activation/Quantizer.py:122-130) against
+    the numpy oracle, bit for bit: int8 and floating-point inputs, windows / strides / paddings per axis."""
+    for it in range(n):
+        kh, kw = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        if rng.integers(0, 2):
+            kw = kh
+        stride = None if rng.integers(0, 3) == 0 else (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        ph, pw = int(rng.integers(0, kh // 2 + 1)), int(rng.integers(0, kw // 2 + 1))
+        B, C = int(rng.integers(1, 4)), int(rng.integers(1, 70))
+        H, W = int(rng.integers(kh, 40)), int(rng.integers(kw, 40))
+        mode = pick(["max", "avg"])
+        dt = pick([torch.int8, torch.float32, torch.float16, torch.bfloat16])
+        if dt == torch.int8:
+            x = torch.from_numpy(rng.integers(-128, 128, size=(B, C, H, W)).astype(np.int8))
+        else:   # values whose cast to int8 truncates, wraps (|v| > 128) and keeps its sign
+            x = torch.from_numpy((rng.standard_normal((B, C, H, W)) * pick([1.0, 40.0, 300.0])).astype(np.float32)).to(dt)
+        y = N.pool2d_to_i8(x.to(dev), (kh, kw), stride, (ph, pw), mode)
+        ref = O.pool2d_to_int8(x.float().numpy(), (kh, kw), stride, (ph, pw), mode)
+        if tuple(y.shape) != ref.shape or not np.array_equal(y.cpu().numpy(), ref):
+            report("pool", f"{mode} {dt}", (B, C, H, W, kh, kw, stride, ph, pw))
+
+
+def fuzz_activation(n):
+    """The dynamic per-tensor activation quantizer: parameters and int8 values against the numpy oracle bit for bit
+    (Qop.py:62-65,157), the Linear / Conv2d built on it against the float64 value of the expression they state."""
+    from quantization_amd.activation import conv2d_dynamic_w8a8, linear_dynamic_w8a8, quantize_tensor_i8
+    g = torch.Generator(device=dev).manual_seed(seed + 6)
+    for it in range(n):
+        kind = int(rng.integers(0, 3))
+        shift, spread = float(rng.normal() * 2), float(np.exp(rng.normal()))
+        if kind == 0:
+            shape = tuple(int(v) for v in rng.integers(1, pick([8, 40, 700]), size=int(rng.integers(1, 4))))
+            x = torch.randn(shape, device=dev, generator=g) * spread + shift
+            q, sc, zp = quantize_tensor_i8(x)
+            rq, rs, rzp = O.quantize_tensor_affine_int8(x.cpu().numpy())
+            if not (np.array_equal(sc.cpu().numpy(), rs) and np.array_equal(zp.cpu().numpy(), rzp)
+                    and np.array_equal(q.cpu().numpy(), rq)):
+                report("activation", "quantize_tensor", (shape, shift, spread))
+            continue
+        has_bias = bool(rng.integers(0, 2))
+        if kind == 1:
+            M, Nn, K = int(rng.integers(1, 300)), int(rng.integers(1, 500)), 16 * int(rng.integers(1, 80))
+            x = torch.randn(M, K, device=dev, generator=g) * spread + shift
+            wq, kw = ri8((Nn, K), g), None
+            args = ("linear", M, Nn, K, has_bias)
+        else:
+            C, Co, k = int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.integers(1, 5))
+            st, pd = int(rng.integers(1, 3)), int(rng.integers(0, 3))
+            H, W = int(rng.integers(k, 30)), int(rng.integers(k, 30))
+            x = torch.randn(int(rng.integers(1, 4)), C, H, W, device=dev, generator=g) * spread + shift
+            wq, kw = ri8((Co, C, k, k), g), dict(stride=st, padding=pd)
+            Nn, args = Co, ("conv", tuple(x.shape), Co, k, st, pd, has_bias)
+        ws = torch.rand(Nn, device=dev, generator=g) * 0.01 + 1e-4
+        b = torch.randn(Nn, device=dev, generator=g) if has_bias else None
+        xq, sx, zx = quantize_tensor_i8(x)
+        x_hat = (xq.double() - zx.double()) * sx.double()   # real zeros in a convolution's padding
+        bd = b.double() if has_bias else torch.zeros(Nn, device=dev, dtype=torch.float64)
+        if kw is None:
+            y = linear_dynamic_w8a8(x, wq, ws, b)
+            ref = (x_hat @ wq.double().t() + bd) * ws.double()
+        else:
+            y = conv2d_dynamic_w8a8(x, wq, ws, b, stride=st, padding=pd)
+            ref = (F.conv2d(x_hat, wq.double(), **kw) + bd.view(1, -1, 1, 1)) * ws.double().view(1, -1, 1, 1)
+        if y.shape != ref.shape or float((y.double() - ref).abs().max()) > 1e-5 * float(ref.abs().max()) + 1e-30:
+            report("activation", "layer", args)
+
+
 FAMILIES = {"gemm": fuzz_gemm, "conv": fuzz_conv, "gemm_w8": fuzz_gemm_w8, "conv_w8": fuzz_conv_w8,
-            "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer, "layers": fuzz_layers}
+            "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer, "layers": fuzz_layers,
+            "pool": fuzz_pool, "activation": fuzz_activation}
 
 
 def run(families, cases, s):
