@@ -360,6 +360,45 @@ def fuzz_layers(n):
                 break
 
 
+def fuzz_layers_wa(n):
+    """Random modules through the weight + activation Quantizer with calibration results set as Chunker.compute_qstats
+    leaves them (quant/Weight_Activation/Chunker.py:79-106: bias' [1,N(,1,1)], scalers of the same shape, a one-element
+    output_zero_point): forward on int8 activations equals (acc + bias') * scalers + output_zero_point evaluated by
+    torch in fp32, one rounding per step (Weight_Activation/Quantizer.py:58-60), bit for bit."""
+    from quantization_amd.quant.Weight_Activation import Quantizer
+    qp = {"weights": {"dtype": torch.int8, "symmetric": True, "affine": "channel", "affine_dim": 0}}
+    g = torch.Generator(device=dev).manual_seed(seed + 7)
+    for it in range(n):
+        torch.manual_seed(seed * 100003 + it)
+        has_bias = bool(rng.integers(0, 2))
+        if rng.integers(0, 2):
+            K, Nn = int(rng.integers(1, 600)), int(rng.integers(1, 400))
+            mod, kw = torch.nn.Linear(K, Nn, bias=has_bias), None
+            xshape, shape, args = (int(rng.integers(1, 40)), K), (1, -1), ("linear", K, Nn, has_bias)
+        else:
+            C, Co, k = int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.integers(1, 5))
+            st, pd = int(rng.integers(1, 3)), int(rng.integers(0, 3))
+            mod = torch.nn.Conv2d(C, Co, k, stride=st, padding=pd, bias=has_bias)
+            H, W = int(rng.integers(k, 30)), int(rng.integers(k, 30))
+            xshape, shape, args = (int(rng.integers(1, 4)), C, H, W), (1, -1, 1, 1), ("conv", C, Co, k, st, pd, H, W, has_bias)
+            kw, Nn = dict(stride=st, padding=pd), Co
+        ql = Quantizer.from_float(module=mod.to(dev), data_metry=qp)
+        rq, _, _ = O.quantize_channel_sym_int8(mod.weight.detach().cpu().numpy())
+        if not np.array_equal(ql.weight.cpu().numpy(), rq):
+            report("layers_wa", "stored weight", args)
+            continue
+        ql.bias = (torch.randn(Nn, device=dev, generator=g) * 200).view(shape)
+        ql.scalers = (torch.rand(Nn, device=dev, generator=g) * 0.01 + 1e-5).view(shape)
+        ql.output_zero_point = torch.tensor([float(rng.integers(-100, 100))], device=dev)
+        x = ri8(xshape, g)
+        y = ql(x)
+        wq = ql.weight.double()
+        acc = (x.double() @ wq.t() if kw is None else F.conv2d(x.double(), wq, **kw)).to(torch.int32)
+        ref = (acc.to(torch.float32) + ql.bias) * ql.scalers + ql.output_zero_point
+        if y.shape != ref.shape or not torch.equal(y, ref):
+            report("layers_wa", "forward", args)
+
+
 def fuzz_pool(n):
     """miq_pool2d_to_i8 (QuantizedMaxPool2d / QuantizedAvgPool2d, quant/Weight_Activation/Quantizer.py:122-130) against
     the numpy oracle, bit for bit: int8 and floating-point inputs, windows / strides / paddings per axis."""
@@ -433,7 +472,7 @@ def fuzz_activation(n):
 
 FAMILIES = {"gemm": fuzz_gemm, "conv": fuzz_conv, "gemm_w8": fuzz_gemm_w8, "conv_w8": fuzz_conv_w8,
             "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer, "layers": fuzz_layers,
-            "pool": fuzz_pool, "activation": fuzz_activation}
+            "layers_wa": fuzz_layers_wa, "pool": fuzz_pool, "activation": fuzz_activation}
 
 
 def run(families, cases, s):
