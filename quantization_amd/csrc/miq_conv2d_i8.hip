@@ -155,79 +155,91 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&r)[4], uint3
 // a source image Ws pixels wide whose channel planes are HWs pixels apart.  MODE 0 gathers single bytes, MODE 1
 // dwords (sub == 1), MODE 2 serves sub == 2 with W % 4 == 0 and Ws % 4 == 0: the four pixels of a thread are
 // the even bytes of one aligned 8-byte run of the source row.
-template <int MODE>
+template <int MODE, int NT = 1>
 __device__ __forceinline__ void nhwc_interior_block(const int8_t* __restrict__ x, int8_t* __restrict__ xp, int Cin, int H,
                                                     int W, int Hp, int Wp, int Cp, int pad, int cblocks, int bx,
                                                     int64_t b, int64_t plane_stride = 0, int sub = 1, int Ws = 0,
                                                     int HWs = 0) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 16];
+    // NT tiles of 64 pixels per workgroup, all their loads issued before the first is used: with one tile a CU's eight
+    // workgroups keep 32 KB in flight, half of what the memory system needs to stay busy.
+    __shared__ __attribute__((aligned(16))) uint32_t tile[NT][64 * 16];
     const int t = threadIdx.x;
     const int HW = H * W;
-    const int p0 = (bx / cblocks) * 64, c0 = (bx % cblocks) * 64;
+    const int p0 = (bx / cblocks) * (64 * NT), c0 = (bx % cblocks) * 64;
     const int cspan = Cp - c0 < 64 ? Cp - c0 : 64;   // channel bytes this block owns per pixel (multiple of 4)
     {
         const int p4 = t & 15, cg = t >> 4;
-        uint32_t r[4], d[4];
-        const int pf = p0 + p4 * 4;   // first of this thread's four pixels
-        int so[4] = {0, 0, 0, 0};     // sub > 1: their offsets inside a source channel plane
-        if (MODE != 1 && sub > 1) {
+        uint32_t r[NT][4];
 #pragma unroll
-            for (int k = 0; k < (MODE == 2 ? 1 : 4); ++k) {
-                const int h = (pf + k) / W, w = pf + k - h * W;
-                so[k] = h * sub * Ws + w * sub;
+        for (int s = 0; s < NT; ++s) {
+            const int pf = p0 + s * 64 + p4 * 4;   // first of this thread's four pixels
+            int so[4] = {0, 0, 0, 0};              // sub > 1: their offsets inside a source channel plane
+            if (MODE != 1 && sub > 1) {
+#pragma unroll
+                for (int k = 0; k < (MODE == 2 ? 1 : 4); ++k) {
+                    const int h = (pf + k) / W, w = pf + k - h * W;
+                    so[k] = h * sub * Ws + w * sub;
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + cg * 4 + j;
-            r[j] = 0u;
-            if (c < Cin) {
-                if constexpr (MODE == 1) {
-                    const int8_t* src = x + (b * Cin + c) * HW + pf;
-                    if (pf < HW) r[j] = *reinterpret_cast<const uint32_t*>(src);
-                } else if constexpr (MODE == 2) {
-                    if (pf < HW) {
-                        const uint2 v = *reinterpret_cast<const uint2*>(x + (b * Cin + c) * HWs + so[0]);
-                        r[j] = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);   // bytes 0, 2 of v.x, then of v.y
-                    }
-                } else if (sub > 1) {
-                    const int8_t* src = x + (b * Cin + c) * HWs;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[so[k]])) << (8 * k);
-                } else {
-                    const int8_t* src = x + (b * Cin + c) * HW + pf;
-                    if (pf + 3 < HW) {   // four pixels inside the plane: one dword load of any alignment
-                        uint32_t v;
-                        __builtin_memcpy(&v, src, 4);
-                        r[j] = v;
-                    } else {
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + cg * 4 + j;
+                r[s][j] = 0u;
+                if (c < Cin) {
+                    if constexpr (MODE == 1) {
+                        const int8_t* src = x + (b * Cin + c) * HW + pf;
+                        if (pf < HW) r[s][j] = *reinterpret_cast<const uint32_t*>(src);
+                    } else if constexpr (MODE == 2) {
+                        if (pf < HW) {
+                            const uint2 v = *reinterpret_cast<const uint2*>(x + (b * Cin + c) * HWs + so[0]);
+                            r[s][j] = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);   // bytes 0, 2 of v.x, then of v.y
+                        }
+                    } else if (sub > 1) {
+                        const int8_t* src = x + (b * Cin + c) * HWs;
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (pf + k < HW) r[j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                            if (pf + k < HW) r[s][j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[so[k]])) << (8 * k);
+                    } else {
+                        const int8_t* src = x + (b * Cin + c) * HW + pf;
+                        if (pf + 3 < HW) {   // four pixels inside the plane: one dword load of any alignment
+                            uint32_t v;
+                            __builtin_memcpy(&v, src, 4);
+                            r[s][j] = v;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (pf + k < HW) r[s][j] |= static_cast<uint32_t>(static_cast<uint8_t>(src[k])) << (8 * k);
+                        }
                     }
                 }
             }
         }
-        transpose4x4_bytes(r, d);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tile[(p4 * 4 + i) * 16 + (cg ^ ((p4 & 3) << 2))] = d[i];
+        for (int s = 0; s < NT; ++s) {
+            uint32_t d[4];
+            transpose4x4_bytes(r[s], d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[s][(p4 * 4 + i) * 16 + (cg ^ ((p4 & 3) << 2))] = d[i];
+        }
     }
     __syncthreads();
     const int pl = t >> 2, part = t & 3;
-    const int p = p0 + pl;
-    if (p < HW && part * 16 < cspan) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&tile[pl * 16 + ((part ^ ((pl >> 2) & 3)) << 2)]);
-        const int h = p / W, w = p - h * W;
-        int8_t* o = xp + ((b * Hp + h + pad) * Wp + w + pad) * Cp + c0 + part * 16;
-        if (plane_stride) o = xp + ((c0 >> 4) + part) * plane_stride + ((b * Hp + h + pad) * Wp + w + pad) * 16;
-        if ((Cp & 15) == 0) {
-            *reinterpret_cast<uint4*>(o) = v;
-        } else {
-            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (part * 16 + k * 4 < cspan) *reinterpret_cast<uint32_t*>(o + k * 4) = vv[k];
+    for (int s = 0; s < NT; ++s) {
+        const int p = p0 + s * 64 + pl;
+        if (p < HW && part * 16 < cspan) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&tile[s][pl * 16 + ((part ^ ((pl >> 2) & 3)) << 2)]);
+            const int h = p / W, w = p - h * W;
+            int8_t* o = xp + ((b * Hp + h + pad) * Wp + w + pad) * Cp + c0 + part * 16;
+            if (plane_stride) o = xp + ((c0 >> 4) + part) * plane_stride + ((b * Hp + h + pad) * Wp + w + pad) * 16;
+            if ((Cp & 15) == 0) {
+                *reinterpret_cast<uint4*>(o) = v;
+            } else {
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (part * 16 + k * 4 < cspan) *reinterpret_cast<uint32_t*>(o + k * 4) = vv[k];
+            }
         }
     }
 }
@@ -371,11 +383,11 @@ struct ConvPrepArgs {
     int sub, Ws, HWs;       // sub > 1: keep every sub-th pixel of every sub-th row of a Ws-wide source image
 };
 
-template <int MODE>
+template <int MODE, int NT = 1>
 __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
-    if (static_cast<int>(blockIdx.x) < a.n_interior) {
-        nhwc_interior_block<MODE>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y,
-                                  a.plane_stride, a.sub, a.Ws, a.HWs);
+    if (static_cast<int>(blockIdx.x) < a.n_interior) {   // (n_interior = tiles of 64 * NT pixels x channel blocks)
+        nhwc_interior_block<MODE, NT>(a.x, a.xp, a.Cin, a.H, a.W, a.Hp, a.Wp, a.Cp, a.pad, a.cblocks, blockIdx.x, blockIdx.y,
+                                      a.plane_stride, a.sub, a.Ws, a.HWs);
         return;
     }
     const uint32_t first = (blockIdx.y * a.n_extra + (blockIdx.x - a.n_interior)) * 256u + threadIdx.x;
@@ -385,6 +397,16 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(ConvPrepArgs a) {
         pack_conv_weight_planar_items(a.w, a.wp, a.weight_total, a.Cin, a.Cout, first, step);
     else
         pack_conv_weight_items(a.w, a.wp, a.weight_total, a.Cin, a.KH, a.KW, a.Cp, a.L, a.Lp, first, step);
+}
+
+// Tiles of 64 pixels a re-layout workgroup takes: two or four where the dword-load form applies and an image has the pixels.
+inline int prep_tiles_per_workgroup(bool dword_loads, int64_t pixels) {
+    const char* sw = dev_switch("MIQ_CONV_PREP_NT");   // developer A/B switch: tiles per workgroup (1, 2 or 4)
+    if (sw && dword_loads && (sw[0] == '1' || sw[0] == '2' || sw[0] == '4')) return sw[0] - '0';
+    // (whole call at batch 256, one / two / four tiles: 64->128 56x56 3x3/2 69.8 / 67.0 / 65.6 us, 128->128 28x28 61.1 / 59.1 /
+    // 59.0, 128->256 28x28 3x3/2 42.8 / 41.2 / 40.8, 256->256 14x14 49.8 / 49.2 / 49.2)
+    if (!dword_loads) return 1;
+    return pixels >= 512 ? 4 : pixels >= 128 ? 2 : 1;
 }
 
 // four dwords that are only dword-aligned in memory (a global store of 16 bytes needs no more)
@@ -2084,13 +2106,19 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
             pa.pad = (int)pad; pa.cblocks = (int)(Cin / 64);
             pa.plane_stride = G.ptot * kChunk;
             pa.Cout = (int)Cout;
-            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * pa.cblocks);
+            const bool dwords = (H * W) % 4 == 0 && miq::aligned(x, 4);
+            const int nt = prep_tiles_per_workgroup(dwords, H * W);
+            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64 * nt) * pa.cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.pitch + 2 * pad * H));
             pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) * (Cin / 16) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
-            if ((H * W) % 4 == 0 && miq::aligned(x, 4))
+            if (dwords && nt == 4)
+                conv_prep_kernel<1, 4><<<pgrid, 256, 0, st>>>(pa);
+            else if (dwords && nt == 2)
+                conv_prep_kernel<1, 2><<<pgrid, 256, 0, st>>>(pa);
+            else if (dwords)
                 conv_prep_kernel<1><<<pgrid, 256, 0, st>>>(pa);
             else
                 conv_prep_kernel<0><<<pgrid, 256, 0, st>>>(pa);
@@ -2105,7 +2133,10 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
             pa.Cin = (int)Cin; pa.H = (int)H; pa.W = (int)W; pa.Hp = (int)G.Hp; pa.Wp = (int)G.Wp; pa.Cp = (int)G.Cp;
             pa.pad = (int)pad; pa.cblocks = cblocks;
             pa.KH = (int)KH; pa.KW = (int)KW; pa.L = (int)G.L; pa.Lp = (int)G.Lp;
-            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64) * cblocks);
+            const bool pairs = G.sub == 2 && W % 4 == 0 && G.Ws % 4 == 0 && (G.Hs * G.Ws) % 8 == 0 && miq::aligned(x, 8);
+            const bool dwords = G.sub == 1 && (H * W) % 4 == 0 && miq::aligned(x, 4);
+            const int nt = prep_tiles_per_workgroup(dwords, H * W);   // (two tiles of 8-byte pair loads: 40.7 -> 44.5 us on 64->128 1x1/2)
+            pa.n_interior = static_cast<int>(miq::ceil_div(H * W, 64 * nt) * cblocks);
             pa.border_total = static_cast<uint32_t>(B * (2 * pad * G.Wp + 2 * pad * H));
             pa.weight_total = (prepacked || dev_switch("MIQ_CONV_SKIP_WPACK")) ? 0u : static_cast<uint32_t>(G.wp_bytes / 4);
             pa.sub = (int)G.sub; pa.Ws = (int)G.Ws; pa.HWs = (int)(G.Hs * G.Ws);
@@ -2113,9 +2144,13 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
             const int64_t extra = miq::ceil_div(static_cast<int64_t>(pa.border_total) * ((G.Cp & 15) ? 1 : G.Cp / 16) + pa.weight_total, 1024);
             pa.n_extra = static_cast<int>(std::min<int64_t>(std::max<int64_t>(miq::ceil_div(extra, B), 1), 4096));
             dim3 pgrid(static_cast<unsigned>(pa.n_interior + pa.n_extra), static_cast<unsigned>(B));
-            if (G.sub == 2 && W % 4 == 0 && G.Ws % 4 == 0 && (G.Hs * G.Ws) % 8 == 0 && miq::aligned(x, 8))
+            if (pairs)
                 conv_prep_kernel<2><<<pgrid, 256, 0, st>>>(pa);
-            else if (G.sub == 1 && (H * W) % 4 == 0 && miq::aligned(x, 4))
+            else if (dwords && nt == 4)
+                conv_prep_kernel<1, 4><<<pgrid, 256, 0, st>>>(pa);
+            else if (dwords && nt == 2)
+                conv_prep_kernel<1, 2><<<pgrid, 256, 0, st>>>(pa);
+            else if (dwords)
                 conv_prep_kernel<1><<<pgrid, 256, 0, st>>>(pa);
             else
                 conv_prep_kernel<0><<<pgrid, 256, 0, st>>>(pa);
