@@ -4,7 +4,7 @@
 cycles: wait for the stage's fetch | barrier | decode of the next stage | the nine taps (with the next fetch's pieces and,
 where a unit has just finished, its rows leaving among them).
 
-    python tools/conv_planar_stamps.py [out: i32|f32|bf16|i8] [cl]"""
+    python tools/conv_planar_stamps.py [out: i32|f32|bf16|i8] [cl|nchw] [Cin,H,Cout ...]"""
 import os
 import sys
 
@@ -18,7 +18,10 @@ from quantization_amd import _native as N  # noqa: E402
 od = {"i32": torch.int32, "f32": torch.float32, "bf16": torch.bfloat16, "i8": torch.int8}[sys.argv[1] if len(sys.argv) > 1 else "i32"]
 cl = len(sys.argv) > 2 and sys.argv[2] == "cl"
 stamps = torch.zeros(512 * 64, dtype=torch.int64, device="cuda")
-for C, H, Co in [(64, 56, 64), (128, 28, 128)]:
+LAYERS = [(64, 56, 64), (128, 28, 128)]
+if len(sys.argv) > 3:   # e.g. 256,14,256
+    LAYERS = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]]
+for C, H, Co in LAYERS:
     x = torch.randint(-128, 128, (256, C, H, H), dtype=torch.int32, device="cuda").to(torch.int8)
     w = torch.randint(-128, 128, (Co, C, 3, 3), dtype=torch.int32, device="cuda").to(torch.int8)
     alpha = torch.rand(Co, device="cuda") * 1e-4
