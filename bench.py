@@ -61,6 +61,20 @@ def event_times(fn, iters):
     return [s.elapsed_time(e) for s, e in evs]
 
 
+def empty_pair_ms(n=20):
+    """What a HIP event pair with nothing between its records measures (median of n): each record is a queue packet of its
+    own, and a pair's interval contains it.  Subtracted from the per-launch pairs of the headline GEMM (5 us of 390), whose
+    result is also capped by the region's time per step."""
+    pairs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in pairs)[n // 2]
+
+
 def median_ms(fn, iters=30, warm=20):
     for _ in range(warm):
         fn()
@@ -461,7 +475,10 @@ def activation_quantizer(N_, dev):
 def quantizer_shapes(N_, dev):
     """The per-channel quantizer on BASELINE config 4's weights and the 4096^2 one of config 2, beside the Llama-3-70B
     shape of the headline record: rotating buffers well past the 256 MiB Infinity Cache, HIP events per launch
-    after a clock ramp, mean.  Algorithmic bytes: sizeof(w) + 1 per element + 12 per row."""
+    after a clock ramp, mean.  (A pair reads about 2 us more than rocprofv3's kernel trace gives the same launch --
+    17.4 us for [4096,4096] there against 19.4 here -- and an empty pair 4.9 us, more than a pair adds to a kernel it
+    brackets: the pair's reading stands uncorrected, the pessimistic one of the two.)  Algorithmic bytes: sizeof(w) + 1 per
+    element + 12 per row."""
     res = {}
     for rows, cols, dt in ((14336, 4096, torch.float32), (14336, 4096, torch.bfloat16), (4096, 14336, torch.float32),
                            (4096, 4096, torch.float32)):
@@ -677,14 +694,7 @@ def main():
     # back, so this is a launch's duration plus the gap to the next).  The kernel's duration is the smaller one; it
     # cannot exceed the step that contains it.
     kt = [a.elapsed_time(b) for a, b in gemm_events]
-    empty = []
-    for _ in range(20):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        b.record()
-        empty.append((a, b))
-    torch.cuda.synchronize()
-    empty_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    empty_ms = empty_pair_ms()
     pair_ms = sum(kt) / len(kt) - empty_ms
     region_ms = region[0].elapsed_time(region[1]) / args.steps
     k_ms = min(pair_ms, region_ms) if world == 1 else pair_ms
@@ -750,7 +760,7 @@ def main():
         }
         extra = {"prewarm_s": PREWARM_S, "kernel_ms_event_pairs": round(pair_ms, 4), "kernel_ms_region": round(region_ms, 4),
                  "quantizer": {"workload": f"per-channel symmetric int8 quantize of fp32 [{QR},{QC}] (5 B/element + 12 B/row)",
-                               "kernel_ms": round(q_ms, 4), "roofline": q_roof}}
+                               "kernel_ms": round(q_ms, 4), "empty_pair_ms": round(empty_ms, 4), "roofline": q_roof}}
         extra.update(extras)
         if world == 1 and not args.no_extras:
             extra["quantizer_shapes"] = quantizer_shapes(N_, dev)
