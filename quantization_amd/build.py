@@ -1,6 +1,6 @@
 """Builds quantization_amd/libmiq.so (the HIP kernels + C ABI) for gfx950 with hipcc.
 
-    python -m quantization_amd.build [--force] [--dev]
+    python -m quantization_amd.build [--force] [--dev] [--ubsan]
 
 hipcc cross-compiles without a GPU.  The .so is built in-tree next to this file so that it
 travels with the source tree; it is never installed into site-packages.
@@ -45,13 +45,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, dev=False):
+# The product's sources with the HOST side compiled under -fsanitize=undefined in trap mode (no sanitizer runtime to load:
+# undefined behaviour ends the process with SIGILL): what tests/test_host_sanitizer.py hands nonsensical sizes to.  Device
+# code is compiled as ever; GPU sanitizers are not used.
+UBSAN_LIB = os.path.join(HERE, "libmiq_ubsan.so")
+UBSAN_FLAGS = ["-Xarch_host", "-fsanitize=undefined,integer-divide-by-zero", "-Xarch_host", "-fsanitize-trap=all"]
+
+
+def build(force=False, verbose=False, dev=False, ubsan=False):
     """Compile each source to an object (in csrc/build/) and link libmiq.so (dev=True: libmiq_dev.so, with
-    the developer switches).  Returns the library's path."""
-    objdir = os.path.join(CSRC, "build", "dev" if dev else "product")
+    the developer switches; ubsan=True: libmiq_ubsan.so, the product with a sanitized host side).  Returns the library's path."""
+    objdir = os.path.join(CSRC, "build", "ubsan" if ubsan else "dev" if dev else "product")
     os.makedirs(objdir, exist_ok=True)
-    lib = DEV_LIB if dev else LIB
-    flags = FLAGS + ([] if dev else ["-DMIQ_NO_DEV_SWITCHES"])
+    lib = UBSAN_LIB if ubsan else DEV_LIB if dev else LIB
+    flags = FLAGS + ([] if dev else ["-DMIQ_NO_DEV_SWITCHES"]) + (UBSAN_FLAGS if ubsan else [])
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "miq.h"), __file__]
     objs, procs = [], []
     for src in SOURCES:
@@ -78,3 +85,5 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--dev" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, dev=True))
+    if "--ubsan" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, ubsan=True))

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kBlock) void quantize_framed_kernel(const void* __r
 int parts_for(int64_t n) {
     // >= 16 elements per thread.  (More, smaller workgroups read a small tensor faster but then all finish together and
     // queue on the arrival counter: 512 workgroups on a [256,4096] tensor took 14.6 us where 128 take 11.)
-    const int64_t want = ceil_div(n, static_cast<int64_t>(kBlock) * 16);
+    constexpr int64_t per = static_cast<int64_t>(kBlock) * 16;
+    const int64_t want = n / per + (n % per != 0);   // (ceil_div would add to an n that may be any int64)
     return static_cast<int>(want < 1 ? 1 : want > kMaxParts ? kMaxParts : want);
 }
 
@@ -394,7 +395,7 @@ extern "C" int miq_dynamic_epilogue_i8(const float* min_max, const float* w_scal
     MIQ_REQUIRE(aligned(min_max, 4) && aligned(w_scale, 4) && aligned(bias, 4) && aligned(w_rowsum, 4) &&
                     aligned(scale_zp, 4) && aligned(alpha, 4) && aligned(corr, 4),
                 MIQ_EALIGN, "miq_dynamic_epilogue_i8: pointers must be 4-byte aligned");
-    const int64_t blocks = ceil_div(n > 0 ? n : 1, kBlock);
+    const int64_t blocks = n / kBlock + 1;
     dynamic_epilogue_kernel<<<static_cast<int>(blocks < 1024 ? blocks : 1024), kBlock, 0, as_stream(stream)>>>(
         min_max, w_scale, bias, w_rowsum, n, scale_zp, alpha, corr);
     return check_launch("dynamic_epilogue_kernel");
@@ -448,15 +449,19 @@ extern "C" int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes
                 "miq_quantize_tensor_i8: negative size");
     MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
                 "miq_quantize_tensor_i8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
+    MIQ_REQUIRE(all_below_2_31({planes, H, W, pad_top, pad_bottom, pad_left, pad_right}), MIQ_ERANGE,
+                "miq_quantize_tensor_i8: planes, H, W and the paddings must each stay below 2^31");
     const int64_t Hf = H + pad_top + pad_bottom, Wf = W + pad_left + pad_right;
-    if (planes * Hf * Wf == 0) return MIQ_OK;
-    MIQ_REQUIRE(scale_zp && q && (x || planes * H * W == 0), MIQ_EINVAL, "miq_quantize_tensor_i8: null pointer");
+    const int64_t n_out = size_product({planes, Hf, Wf}), n_in = size_product({planes, H, W});
+    MIQ_REQUIRE(n_out >= 0, MIQ_ERANGE, "miq_quantize_tensor_i8: the output's element count does not fit 62 bits");
+    if (n_out == 0) return MIQ_OK;
+    MIQ_REQUIRE(scale_zp && q && (x || n_in == 0), MIQ_EINVAL, "miq_quantize_tensor_i8: null pointer");
     MIQ_REQUIRE(aligned(x, x_dtype == MIQ_F32 ? 4 : 2) && aligned(scale_zp, 4), MIQ_EALIGN,
                 "miq_quantize_tensor_i8: x / scale_zp not aligned to their element size");
     hipStream_t st = as_stream(stream);
     const bool framed = pad_top || pad_bottom || pad_left || pad_right;
     if (!framed) {
-        const int64_t n = planes * H * W;
+        const int64_t n = n_in;
         const int per = x_dtype == MIQ_F32 ? 4 : 8;
         const int vector = aligned(x, 16) && aligned(q, per);
         const int64_t blocks = ceil_div(ceil_div(n, per), kBlock);
@@ -468,7 +473,8 @@ extern "C" int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes
         }
         return check_launch("quantize_tensor_kernel");
     }
-    MIQ_REQUIRE(planes * Hf < (1ll << 32) && Hf < (1ll << 31) && Wf < (1ll << 31) && H < (1ll << 31) && W < (1ll << 31), MIQ_ERANGE,
+    const int64_t rows_out = size_product({planes, Hf});
+    MIQ_REQUIRE(rows_out >= 0 && rows_out < (1ll << 32) && Hf < (1ll << 31) && Wf < (1ll << 31), MIQ_ERANGE,
                 "miq_quantize_tensor_i8: at most 2^32 output rows");
     const int64_t items = planes * Hf * ceil_div(Wf, 4);
     const int64_t blocks = ceil_div(items, kBlock);
@@ -493,7 +499,9 @@ extern "C" int miq_dynamic_quantize_i8(const void* x, int x_dtype, int64_t plane
                                        float* corr, int8_t* q, void* workspace, size_t workspace_bytes, unsigned* counter,
                                        void* stream) {
     MIQ_REQUIRE(planes >= 0 && H >= 0 && W >= 0, MIQ_EINVAL, "miq_dynamic_quantize_i8: negative size");
-    if (int rc = miq_dynamic_quant_params_i8(x, x_dtype, planes * H * W, w_scale, bias, w_rowsum, channels, scale_zp, alpha, corr,
+    const int64_t n = size_product({planes, H, W});
+    MIQ_REQUIRE(n >= 0, MIQ_ERANGE, "miq_dynamic_quantize_i8: the tensor's element count does not fit 62 bits");
+    if (int rc = miq_dynamic_quant_params_i8(x, x_dtype, n, w_scale, bias, w_rowsum, channels, scale_zp, alpha, corr,
                                              workspace, workspace_bytes, counter, stream))
         return rc;
     return miq_quantize_tensor_i8(x, x_dtype, planes, H, W, pad_top, pad_bottom, pad_left, pad_right, scale_zp, q, stream);
@@ -518,6 +526,7 @@ DynLayout dyn_layout(int64_t M, int64_t N, int64_t K) {
 
 extern "C" size_t miq_linear_dynamic_w8a8_workspace(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!all_below_2_31({M, N, K}) || M * K >= (1ll << 31) || N * K >= (1ll << 31)) return 0;   // (the call answers MIQ_ERANGE)
     return dyn_layout(M, N, K).total;
 }
 
@@ -527,7 +536,8 @@ extern "C" int miq_linear_dynamic_w8a8(const void* x, int x_dtype, const int8_t*
     MIQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, MIQ_EINVAL, "miq_linear_dynamic_w8a8: negative size");
     if (M == 0 || N == 0) return MIQ_OK;
     MIQ_REQUIRE(K > 0, MIQ_EINVAL, "miq_linear_dynamic_w8a8: K must be positive (the activation's statistics need elements)");
-    MIQ_REQUIRE(M * K < (1ll << 31), MIQ_ERANGE, "miq_linear_dynamic_w8a8: M * K must stay below 2^31");
+    MIQ_REQUIRE(all_below_2_31({M, N, K}) && M * K < (1ll << 31) && N * K < (1ll << 31), MIQ_ERANGE,
+                "miq_linear_dynamic_w8a8: M * K and N * K must stay below 2^31");
     const DynLayout L = dyn_layout(M, N, K);
     MIQ_REQUIRE(workspace && workspace_bytes >= L.total, MIQ_EWORKSPACE,
                 "miq_linear_dynamic_w8a8: needs %zu bytes of workspace (got %zu)", L.total, workspace_bytes);

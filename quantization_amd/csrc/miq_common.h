@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
 
 #include "miq.h"
 
@@ -34,6 +35,34 @@ inline const char* dev_switch(const char* name) {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// What an entry point does with the sizes it is handed BEFORE any arithmetic on them (signed overflow is undefined
+// behaviour, and a size query given nonsense must answer 0, not trap): every size, count, stride, padding in [0, 2^31),
+// so that a product of two fits int64, and longer products through size_product().  The host code is built with
+// -fsanitize=undefined for a test that hands every entry point such sizes (tests/test_host_sanitizer.py).
+inline bool all_below_2_31(std::initializer_list<int64_t> v) {
+    for (int64_t d : v)
+        if (d < 0 || d >= (1ll << 31)) return false;
+    return true;
+}
+// The product of non-negative sizes, or -1 when a factor is negative or the product reaches 2^62.
+inline int64_t size_product(std::initializer_list<int64_t> f) {
+    for (int64_t v : f)
+        if (v < 0) return -1;
+    int64_t p = 1;
+    for (int64_t v : f) {
+        if (v == 0) return 0;
+        if (__builtin_mul_overflow(p, v, &p) || p >= (1ll << 62)) return -1;
+    }
+    return p;
+}
+
+// The same product, held at 2^60 where it would pass it: for geometry that is computed first and range-checked after
+// (every byte count a kernel accepts is below 2^31, so a held value is refused like any other that is too large).
+inline int64_t sat_product(std::initializer_list<int64_t> f) {
+    const int64_t p = size_product(f);
+    return p < 0 || p > (1ll << 60) ? (1ll << 60) : p;
+}
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

@@ -371,6 +371,8 @@ extern "C" size_t miq_conv2d_general_workspace(int x_dtype, int64_t B, int64_t C
                                                int64_t KW, int64_t stride_h, int64_t stride_w, int64_t pad_top, int64_t pad_bottom,
                                                int64_t pad_left, int64_t pad_right, int64_t dil_h, int64_t dil_w, int64_t groups) {
     if (groups != 1) return 0;
+    if (!miq::all_below_2_31({B, Cin, H, W, Cout, KH, KW, stride_h, stride_w, pad_top, pad_bottom, pad_left, pad_right, dil_h, dil_w}))
+        return 0;
     if (KH == 1) dil_h = 1;   // as in miq_conv2d_general: a filter one tap high / wide has no dilation
     if (KW == 1) dil_w = 1;
     if (x_dtype == MIQ_I8)
@@ -393,6 +395,10 @@ extern "C" int miq_conv2d_general(const void* x, int x_dtype, const int8_t* w, i
     MIQ_REQUIRE(stride_h > 0 && stride_w > 0 && dil_h > 0 && dil_w > 0 && pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 &&
                     pad_right >= 0,
                 MIQ_EINVAL, "miq_conv2d_general: stride and dilation must be positive, padding non-negative");
+    MIQ_REQUIRE(miq::all_below_2_31({B, Cin, H, W, Cout, groups}), MIQ_ERANGE, "miq_conv2d_general: sizes must stay below 2^31");
+    MIQ_REQUIRE(KH < (1 << 15) && KW < (1 << 15) && stride_h < (1 << 15) && stride_w < (1 << 15) && dil_h < (1 << 15) &&
+                    dil_w < (1 << 15) && pad_top < (1 << 15) && pad_bottom < (1 << 15) && pad_left < (1 << 15) && pad_right < (1 << 15),
+                MIQ_ERANGE, "miq_conv2d_general: filter size, stride, dilation and padding must stay below 32768");
     MIQ_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, MIQ_EINVAL,
                 "miq_conv2d_general: groups (%lld) must divide Cin (%lld) and Cout (%lld)", (long long)groups, (long long)Cin,
                 (long long)Cout);
@@ -409,8 +415,9 @@ extern "C" int miq_conv2d_general(const void* x, int x_dtype, const int8_t* w, i
     MIQ_REQUIRE(H + pad_top + pad_bottom >= eh && W + pad_left + pad_right >= ew, MIQ_EINVAL,
                 "miq_conv2d_general: dilated filter larger than the padded input");
     const int64_t Ho = (H + pad_top + pad_bottom - eh) / stride_h + 1, Wo = (W + pad_left + pad_right - ew) / stride_w + 1;
-    const int64_t R = Cin / groups * KH * KW;
-    MIQ_REQUIRE(Cin * H * W < (1ll << 31) && Ho * Wo < (1ll << 31) && Cout * R < (1ll << 31) && H + pad_top + pad_bottom < (1ll << 30) &&
+    const int64_t R = miq::sat_product({Cin / groups, KH, KW});
+    MIQ_REQUIRE(miq::sat_product({Cin, H, W}) < (1ll << 31) && Ho * Wo < (1ll << 31) && miq::sat_product({Cout, R}) < (1ll << 31) &&
+                    H + pad_top + pad_bottom < (1ll << 30) &&
                     W + pad_left + pad_right < (1ll << 30) && eh < (1ll << 30) && ew < (1ll << 30),
                 MIQ_ERANGE, "miq_conv2d_general: shape too large");
     if (B == 0) return MIQ_OK;

@@ -53,6 +53,10 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
                int64_t pad, ConvGeom& g, bool relayout = true) {   // relayout = false: the caller's channels-last form is staged as it is
     g = ConvGeom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 1, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    // (sizes first: below 2^31 each, filter / stride / padding below 2^15, so that the sums and two-factor products below
+    // stay inside int64; longer products are held at 2^60 and refused by the range checks of whoever asked)
+    if (!all_below_2_31({B, Cin, H, W, Cout}) || KH >= (1 << 15) || KW >= (1 << 15) || stride >= (1 << 15) || pad >= (1 << 15))
+        return false;
     const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
     if (relayout && KH == 1 && KW == 1 && pad == 0 && stride > 1 && H * W < (1ll << 30) && !(ss && ss[0] == '0')) {
         g.sub = stride;
@@ -69,31 +73,32 @@ bool make_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64
     g.L = KW * g.Cp;
     g.Lp = round_up(g.L, kChunk);
     g.Kp = KH * g.Lp;
-    g.M = B * g.Ho * g.Wo;
-    g.xp_bytes = B * g.Hp * g.Wp * g.Cp;
-    g.wp_bytes = Cout * g.Kp;
+    g.M = sat_product({B, g.Ho, g.Wo});
+    g.xp_bytes = sat_product({B, g.Hp, g.Wp, g.Cp});
+    g.wp_bytes = sat_product({Cout, g.Kp});
     // The 3 x 3 / stride 1 kernel: whole 64-channel groups, four output pixels per 16-byte store, and a
     // patch (the padded rows a tile touches, two more, two pixels) that fits the LDS planes.
     g.pitch = round_up(g.Wp, 4);
-    g.ptot = B * g.Hp * g.pitch;
+    g.ptot = sat_product({B, g.Hp, g.pitch});
     const char* sw = dev_switch("MIQ_CONV_PLANAR");   // developer A/B switch: 0 = im2col-order kernel for every layer
     g.planar = false;
-    if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && g.M >= 4 * kTM && !(sw && sw[0] == '0')) {
+    if (relayout && KH == 3 && KW == 3 && stride == 1 && Cin % 64 == 0 && g.M >= 4 * kTM && g.M < (1ll << 31) &&
+        !(sw && sw[0] == '0')) {
         // Images whose pixel count is no multiple of four (7 x 7) leave pixel by pixel; their rows then need no whole
         // dwords of pixels either, and a tile holds more of them (eight 7 x 7 images instead of six).
         if ((g.Ho * g.Wo) % 4 != 0) {
             g.pitch = g.Wp;
-            g.ptot = B * g.Hp * g.pitch;
+            g.ptot = sat_product({B, g.Hp, g.pitch});
         }
         g.planar = patch_tiling(g.Ho * g.Wo, g.Wo, g.Hp, g.pitch, kPlaneSlots, g.group);
         if (!g.planar) {
             g.pitch = round_up(g.Wp, 4);
-            g.ptot = B * g.Hp * g.pitch;
+            g.ptot = sat_product({B, g.Hp, g.pitch});
         }
     }
     if (g.planar) {
-        g.xp_bytes = g.ptot * Cin;
-        g.wp_bytes = ceil_div(Cout, 64) * (Cin / 64) * kWStageBytes;
+        g.xp_bytes = sat_product({g.ptot, Cin});
+        g.wp_bytes = sat_product({ceil_div(Cout, 64), Cin / 64, kWStageBytes});
     }
     return true;
 }
@@ -1994,12 +1999,17 @@ static bool stream_choice(bool chosen) {
 
 static PackedWeight packed_weight_layout(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     PackedWeight pw{};
+    // (sizes as make_geom bounds them; what does not fit is held at 2^60, beyond every caller's 2 GiB limit)
+    if (!miq::all_below_2_31({Cin, Cout}) || KH < 0 || KW < 0 || KH >= (1 << 15) || KW >= (1 << 15)) {
+        pw.rows_bytes = pw.total = 1ll << 60;
+        return pw;
+    }
     const int64_t Lp = miq::round_up(KW * miq::round_up(Cin, kCinAlign), kChunk);
-    pw.rows_bytes = Cout * KH * Lp;
+    pw.rows_bytes = miq::sat_product({Cout, KH, Lp});
     pw.total = pw.rows_bytes;
     if (KH == 3 && KW == 3 && Cin % 64 == 0) {
         pw.planar_at = miq::round_up(pw.rows_bytes, 256);
-        pw.planar_bytes = miq::ceil_div(Cout, 64) * (Cin / 64) * kWStageBytes;
+        pw.planar_bytes = miq::sat_product({miq::ceil_div(Cout, 64), Cin / 64, kWStageBytes});
         pw.total = pw.planar_at + pw.planar_bytes;
     }
     return pw;
@@ -2009,6 +2019,7 @@ extern "C" size_t miq_conv2d_i8_workspace(int64_t B, int64_t Cin, int64_t H, int
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvGeom g;
     if (!make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, g)) return 0;
+    if (g.xp_bytes >= (1ll << 31) || g.wp_bytes >= (1ll << 31)) return 0;   // (the call answers MIQ_ERANGE)
     return static_cast<size_t>(miq::round_up(g.xp_bytes, 256) + miq::round_up(g.wp_bytes, 256));
 }
 
@@ -2053,7 +2064,8 @@ static int conv2d_i8_run(bool prepacked, const int8_t* x, const int8_t* w, int64
 
     // 3 x 3 / stride 1 layers whose rows are whole dwords: the patch kernel stages the NCHW activation itself (no padded
     // copy, no re-layout launch); only the filters are re-laid, into the workspace.
-    if (G.planar && G.group == 1 && W % 4 == 0 && (G.Ho * G.Wo) % 4 == 0 && miq::aligned(x, 4) && B * Cin * H * W < (1ll << 31) &&
+    if (G.planar && G.group == 1 && W % 4 == 0 && (G.Ho * G.Wo) % 4 == 0 && miq::aligned(x, 4) &&
+        miq::sat_product({B, Cin, H, W}) < (1ll << 31) &&
         !(dev_switch("MIQ_CONV_DIRECT") && dev_switch("MIQ_CONV_DIRECT")[0] == '0')) {
         const int64_t HoWo = G.Ho * G.Wo, tiles_img = miq::ceil_div(HoWo, kTM);
         int64_t rows = 0;
@@ -2245,6 +2257,7 @@ extern "C" size_t miq_conv2d_i8_prepacked_workspace(int64_t B, int64_t Cin, int6
                                                     int64_t KW, int64_t stride, int64_t pad) {
     ConvGeom g;
     if (!make_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, g)) return 0;
+    if (g.xp_bytes >= (1ll << 31)) return 0;   // (the call answers MIQ_ERANGE)
     return static_cast<size_t>(miq::round_up(g.xp_bytes, 256));
 }
 
@@ -2275,6 +2288,10 @@ bool make_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
         pt < 0 || pb < 0 || pl < 0 || pr < 0)
         return false;
+    // (as make_geom: sizes below 2^31, filter / stride / dilation / padding below 2^15, long products held at 2^60)
+    if (!all_below_2_31({B, Cin, H, W, Cout})) return false;
+    for (int64_t v : {KH, KW, sh, sw, dh, dw, pt, pb, pl, pr})
+        if (v >= (1 << 15)) return false;
     const int64_t eh = dh * (KH - 1) + 1, ew = dw * (KW - 1) + 1;
     if (H + pt + pb < eh || W + pl + pr < ew) return false;
     g.P = std::max(std::max(pt, pb), std::max(pl, pr));
@@ -2285,12 +2302,12 @@ bool make_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
     g.kw_run = dw == 1 ? KW : 1;        // taps of one "row"
     g.L = g.kw_run * g.Cp;
     g.Lp = round_up(g.L, kChunk);
-    g.Kp = g.rows * g.Lp;
+    g.Kp = sat_product({g.rows, g.Lp});
     g.Ho = (H + pt + pb - eh) / sh + 1;
     g.Wo = (W + pl + pr - ew) / sw + 1;
-    g.M = B * g.Ho * g.Wo;
-    g.xp_bytes = B * g.Hp * g.Wp * g.Cp;
-    g.wp_bytes = Cout * g.Kp;
+    g.M = sat_product({B, g.Ho, g.Wo});
+    g.xp_bytes = sat_product({B, g.Hp, g.Wp, g.Cp});
+    g.wp_bytes = sat_product({Cout, g.Kp});
     return true;
 }
 
@@ -2391,7 +2408,8 @@ int conv2d_i8_dense(const int8_t* x, const int8_t* w, int64_t B, int64_t Cin, in
 // ---- channels-last entry points ---------------------------------------------------------------------
 extern "C" size_t miq_conv2d_i8_packed_weight_bytes(int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
-    return static_cast<size_t>(packed_weight_layout(Cin, Cout, KH, KW).total);
+    const int64_t total = packed_weight_layout(Cin, Cout, KH, KW).total;
+    return total < (1ll << 31) ? static_cast<size_t>(total) : 0;   // (miq_conv2d_i8_pack_weight answers MIQ_ERANGE)
 }
 
 extern "C" int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int8_t* wp,
@@ -2400,9 +2418,9 @@ extern "C" int miq_conv2d_i8_pack_weight(const int8_t* w, int64_t Cin, int64_t C
     if (Cout == 0) return MIQ_OK;
     MIQ_REQUIRE(w && wp, MIQ_EINVAL, "miq_conv2d_i8_pack_weight: null pointer");
     MIQ_REQUIRE(miq::aligned(wp, 16), MIQ_EALIGN, "miq_conv2d_i8_pack_weight: wp must be 16-byte aligned");
-    const int64_t Cp = miq::round_up(Cin, kCinAlign), L = KW * Cp, Lp = miq::round_up(L, kChunk);
     const PackedWeight pw = packed_weight_layout(Cin, Cout, KH, KW);
     MIQ_REQUIRE(pw.total < (1ll << 31), MIQ_ERANGE, "miq_conv2d_i8_pack_weight: packed weight beyond 2 GiB");
+    const int64_t Cp = miq::round_up(Cin, kCinAlign), L = KW * Cp, Lp = miq::round_up(L, kChunk);
     const uint32_t total = static_cast<uint32_t>(pw.rows_bytes / 4);
     const int wgrid = static_cast<int>(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
     pack_conv_weight_kernel<<<wgrid, 256, 0, miq::as_stream(stream)>>>(w, wp, total, (int)Cin, (int)KH, (int)KW, (int)Cp, (int)L,
@@ -2432,9 +2450,10 @@ extern "C" int miq_conv2d_i8_nhwc(const int8_t* x, const int8_t* wp, int64_t B, 
     if (G.M == 0 || Cout == 0) return MIQ_OK;
     MIQ_REQUIRE(x && wp && out, MIQ_EINVAL, "miq_conv2d_i8_nhwc: null pointer");
     MIQ_REQUIRE(out_dtype == MIQ_I32 || alpha, MIQ_EINVAL, "miq_conv2d_i8_nhwc: alpha is required for a dequantised output");
+    MIQ_REQUIRE(out_pad < (1ll << 15), MIQ_ERANGE, "miq_conv2d_i8_nhwc: out_pad must stay below 32768");
     const int64_t Hop = G.Ho + 2 * out_pad, Wop = G.Wo + 2 * out_pad;
     MIQ_REQUIRE(G.xp_bytes < (1ll << 31) && G.wp_bytes < (1ll << 31) && G.M < (1ll << 31) && B < 65536 && G.Hp < 65536 &&
-                    B * Hop * Wop * Cout < (1ll << 31),
+                    miq::sat_product({B, Hop, Wop, Cout}) < (1ll << 31),
                 MIQ_ERANGE, "miq_conv2d_i8_nhwc: activations, packed weights and output are indexed with 31 bits");
     MIQ_REQUIRE(G.Kp / kChunk <= 4096, MIQ_ERANGE, "miq_conv2d_i8_nhwc: KH*KW*Cin too large (%lld > 65536)", (long long)G.Kp);
     const size_t esz = out_dtype == MIQ_I8 ? 1 : out_dtype == MIQ_BF16 ? 2 : 4;

@@ -1520,8 +1520,13 @@ int gemm_i8_call(const char* who, bool extended, bool scratch_mode, const int8_t
 
 }  // namespace
 
+// What validate() accepts (M*K and N*K below 2^31): anything else gets no workspace here and MIQ_ERANGE from the call.
+bool sizes_in_range(int64_t M, int64_t N, int64_t K) {
+    return miq::all_below_2_31({M, N, K}) && M * K < (1ll << 31) && N * K < (1ll << 31);
+}
+
 extern "C" size_t miq_gemm_i8_workspace(int w_layout, int64_t M, int64_t N, int64_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || !sizes_in_range(M, N, K)) return 0;
     // (alignment of the caller's pointers is unknown here: a problem that ends on the one-thread-per-output
     // kernel needs no slabs, so this is an upper bound for it)
     return transposed_bytes(w_layout, N, K) + make_schedule(M, N, K, K % 16 == 0).slab_bytes;
@@ -1535,7 +1540,7 @@ extern "C" int miq_gemm_i8(const int8_t* A, const int8_t* W, int w_layout, int64
 }
 
 extern "C" size_t miq_gemm_i8_ex_workspace(int w_layout, int out_layout, int64_t M, int64_t N, int64_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || !sizes_in_range(M, N, K)) return 0;
     const bool tr = out_layout == MIQ_OUT_NM;
     return transposed_bytes(w_layout, N, K) + make_schedule(tr ? N : M, tr ? M : N, K, K % 16 == 0).slab_bytes;
 }

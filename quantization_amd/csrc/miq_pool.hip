@@ -287,13 +287,17 @@ extern "C" int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C
                 (long long)B, (long long)C, (long long)H, (long long)W);
     MIQ_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, MIQ_EINVAL,
                 "miq_pool2d_to_i8: bad window (kernel %dx%d stride %dx%d pad %dx%d)", kh, kw, sh, sw, ph, pw);
+    MIQ_REQUIRE(kh < (1 << 15) && kw < (1 << 15) && sh < (1 << 15) && sw < (1 << 15) && ph < (1 << 15) && pw < (1 << 15), MIQ_ERANGE,
+                "miq_pool2d_to_i8: window, stride and padding must stay below 32768");
     // torch's rule (pad should be at most half of the kernel): no window lies wholly in the padding
     MIQ_REQUIRE(2 * ph <= kh && 2 * pw <= kw, MIQ_EINVAL, "miq_pool2d_to_i8: pad must be at most half the kernel size");
     MIQ_REQUIRE(mode == MIQ_POOL_MAX || mode == MIQ_POOL_AVG, MIQ_EINVAL, "miq_pool2d_to_i8: unknown mode %d", mode);
     MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16 || x_dtype == MIQ_I8, MIQ_EINVAL,
                 "miq_pool2d_to_i8: x_dtype must be MIQ_F32, MIQ_F16, MIQ_BF16 or MIQ_I8 (got %d)", x_dtype);
+    const int64_t planes = miq::size_product({B, C});
+    MIQ_REQUIRE(H < (1ll << 31) && W < (1ll << 31) && planes >= 0 && planes < (1ll << 40), MIQ_ERANGE,
+                "miq_pool2d_to_i8: shape too large");
     MIQ_REQUIRE(H + 2 * ph >= kh && W + 2 * pw >= kw, MIQ_EINVAL, "miq_pool2d_to_i8: window larger than the padded input");
-    MIQ_REQUIRE(H < (1ll << 31) && W < (1ll << 31) && B * C < (1ll << 40), MIQ_ERANGE, "miq_pool2d_to_i8: shape too large");
     if (B == 0 || C == 0) return MIQ_OK;
     MIQ_REQUIRE(x && out, MIQ_EINVAL, "miq_pool2d_to_i8: null pointer");
     const size_t esz = x_dtype == MIQ_F32 ? 4 : x_dtype == MIQ_I8 ? 1 : 2;
@@ -301,7 +305,7 @@ extern "C" int miq_pool2d_to_i8(const void* x, int x_dtype, int64_t B, int64_t C
     PoolArgs a{};
     a.x = x;
     a.out = out;
-    a.planes = B * C;
+    a.planes = planes;
     a.H = static_cast<int>(H);
     a.W = static_cast<int>(W);
     a.Ho = static_cast<int>((H + 2 * ph - kh) / sh + 1);

@@ -533,7 +533,8 @@ extern "C" int miq_quantize_rows_given_i8(const void* w, int w_dtype, int64_t ro
 extern "C" int miq_dequantize_channels_f32(const float* y, const float* scale, const float* zp, int64_t outer,
                                            int64_t channels, int64_t inner, float* out, void* stream) {
     MIQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0, MIQ_EINVAL, "miq_dequantize_channels_f32: negative size");
-    const int64_t total = outer * channels * inner;
+    const int64_t total = miq::size_product({outer, channels, inner});
+    MIQ_REQUIRE(total >= 0, MIQ_ERANGE, "miq_dequantize_channels_f32: outer * channels * inner does not fit 62 bits");
     if (total == 0) return MIQ_OK;
     MIQ_REQUIRE(y && scale && out, MIQ_EINVAL, "miq_dequantize_channels_f32: null pointer");
     dequantize_channels_kernel<<<grid_for(miq::ceil_div(total, kBlock)), kBlock, 0, miq::as_stream(stream)>>>(
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(kBlock) void epilogue_channels_kernel(const float* 
 extern "C" int miq_epilogue_channels_f32(const float* y, const float* bias, const float* alpha, float beta,
                                          int64_t outer, int64_t channels, int64_t inner, float* out, void* stream) {
     MIQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0, MIQ_EINVAL, "miq_epilogue_channels_f32: negative size");
-    const int64_t total = outer * channels * inner;
+    const int64_t total = miq::size_product({outer, channels, inner});
+    MIQ_REQUIRE(total >= 0, MIQ_ERANGE, "miq_epilogue_channels_f32: outer * channels * inner does not fit 62 bits");
     if (total == 0) return MIQ_OK;
     MIQ_REQUIRE(y && alpha && out, MIQ_EINVAL, "miq_epilogue_channels_f32: null pointer");
     epilogue_channels_kernel<<<grid_for(miq::ceil_div(total, kBlock)), kBlock, 0, miq::as_stream(stream)>>>(
