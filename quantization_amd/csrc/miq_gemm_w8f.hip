@@ -885,6 +885,10 @@ bool make_conv_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cou
                        int64_t pad, ConvW8Geom& g) {
     g = ConvW8Geom{B, Cin, H, W, Cout, KH, KW, stride, pad, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, H, W};
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return false;
+    // (sizes first: below 2^31 each, filter / stride / padding below 2^15, so that the sums and two-factor products below
+    // stay inside int64; longer products are held at 2^60 and refused by the range checks of whoever asked)
+    if (!all_below_2_31({B, Cin, H, W, Cout}) || KH >= (1 << 15) || KW >= (1 << 15) || stride >= (1 << 15) || pad >= (1 << 15))
+        return false;
     const char* ss = dev_switch("MIQ_CONV_SUBSAMPLE");   // developer A/B switch: 0 = re-lay the whole image
     if (KH == 1 && KW == 1 && pad == 0 && stride > 1 && !(ss && ss[0] == '0')) {
         g.sub = stride;
@@ -901,10 +905,17 @@ bool make_conv_w8_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cou
     g.L = KW * g.Cp;
     g.Lp = round_up(g.L, 16);
     g.K = KH * g.Lp;
-    g.M = B * g.Ho * g.Wo;
-    g.plane_bytes = round_up(B * g.Hp * g.Wp * g.Cp * 2, 256);
-    g.wp_bytes = round_up(Cout * g.K, 256);
+    g.M = sat_product({B, g.Ho, g.Wo});
+    g.plane_bytes = round_up(sat_product({B, g.Hp, g.Wp, g.Cp, 2}), 256);
+    g.wp_bytes = round_up(sat_product({Cout, g.K}), 256);
     return true;
+}
+
+// The whole problem inside what the kernels index with 31 bits (the condition the entry points refuse on): the other
+// geometries (patch, stem) are computed only for such problems, whose products then stay far inside int64.
+inline bool conv_w8_in_range(const ConvW8Geom& g, int planes) {
+    return sat_product({planes, g.plane_bytes}) < (1ll << 31) && g.wp_bytes < (1ll << 31) && g.M < (1ll << 31) &&
+           sat_product({g.K, g.Lp}) < (1ll << 31);
 }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
@@ -1164,6 +1175,8 @@ struct PatchW8Args {
     uint32_t xp_bytes, wp_bytes;
     int group, B, img_slots, pix_end;
     int ragged;           // HoWo % 4 != 0 (7 x 7 images): a lane's four pixels may lie in two images, stored one by one
+    int ablate;           // developer library, timing only (wrong results): 1 = every patch fetch out of range (no memory
+                          // traffic), 2 = every output store out of range (dropped)
 };
 
 // NCHW activation -> chunk planes (zero border, zero slots behind a row's last pixel).  One thread per eight channels of
@@ -1249,7 +1262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.xp, (g.ablate & 1) ? 0u : g.xp_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.wp, g.wp_bytes);
     // Filters stay resident when those of all the layer's groups fit beside the two patches (up to 72 KiB: 64 input
     // channels): a workgroup keeps one channel tile, so they are fetched once; otherwise a group's filters travel with
@@ -1364,7 +1377,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
     const uint32_t img_bytes = static_cast<uint32_t>(g.Cout) * g.HoWo * kEsz;
     auto image_of = [&](const Unit& u) {   // (the unit's images that exist: stores to one past the batch are dropped)
         const uint32_t n = static_cast<uint32_t>(g.B) - u.b < static_cast<uint32_t>(g.group) ? g.B - u.b : g.group;
-        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, n * img_bytes);
+        return make_rsrc(static_cast<char*>(g.out) + static_cast<size_t>(u.b) * img_bytes, (g.ablate & 2) ? 0u : n * img_bytes);
     };
 
     // weight fragment of k-group lane >> 4 (two planes: of (lane >> 4) & 1): eight bf16 per lane
@@ -1454,6 +1467,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_w8_kernel(PatchW8Args g)
                     // the finished unit's row t leaves behind this tap's MFMAs, as a block of its own behind a branch
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (kPiecesFirst) {
+                        // (rows spread over all the unit's stages instead of its first: 226 -> 308 us whole call on
+                        // 64->64 56x56 at batch 256, every stage then waits for stores)
                         if constexpr (t >= 2) {
                             if (flush) stores += store_step(rout, prev, std::integral_constant<int, t - 2>{});
                         }
@@ -1587,6 +1602,7 @@ int run_patch_w8(const PatchW8Geom& P, const void* x, int x_dtype, const int8_t*
     a.wo_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(P.Wo)) + 1u;
     a.xp_bytes = (uint32_t)P.xp_bytes; a.wp_bytes = (uint32_t)P.wp_bytes;
     a.ragged = (P.Ho * P.Wo) % 4 != 0;
+    if (const char* ab = dev_switch("MIQ_W8_PATCH_ABLATE")) a.ablate = atoi(ab);
     set_patch_units(a, B, P.Ho * P.Wo, P.Hp, P.pitch, P.group);
     const int64_t esz = out_dtype == MIQ_BF16 ? 2 : 4;
     const bool stream_out = B * Cout * P.Ho * P.Wo * esz >= (192ll << 20) && out_dtype != MIQ_BF16;
@@ -1907,6 +1923,9 @@ int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w
 
 extern "C" size_t miq_gemm_w8_workspace(int x_dtype, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return 0;
+    // what miq_gemm_w8 accepts; anything else gets no workspace here and MIQ_ERANGE from the call (and no arithmetic is
+    // done on sizes that may be any int64: a query must answer, not trap)
+    if (!miq::all_below_2_31({M, N, K}) || M * K >= (1ll << 29) || N * K >= (1ll << 31)) return 0;
     return 2 * plane_bytes(x_dtype, M, K) + w8f_slab_bytes(M, N, K, x_dtype == MIQ_F32 ? 2 : 1);
 }
 
@@ -2052,6 +2071,7 @@ extern "C" size_t miq_conv2d_w8_workspace(int x_dtype, int64_t B, int64_t Cin, i
                                           int64_t KW, int64_t stride, int64_t pad) {
     ConvW8Geom G;
     if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
+    if (!conv_w8_in_range(G, conv_w8_planes(x_dtype))) return 0;   // (the call answers MIQ_ERANGE)
     const PatchW8Geom P = make_patch_w8_geom(conv_w8_planes(x_dtype), B, Cin, H, W, Cout, KH, KW, stride, pad);
     if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256) + round_up(P.wp_bytes, 256));
     const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
@@ -2063,6 +2083,7 @@ extern "C" size_t miq_conv2d_w8_prepacked_workspace(int x_dtype, int64_t B, int6
                                                     int64_t KH, int64_t KW, int64_t stride, int64_t pad) {
     ConvW8Geom G;
     if (!make_conv_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad, G) || G.M == 0 || Cout == 0) return 0;
+    if (!conv_w8_in_range(G, conv_w8_planes(x_dtype))) return 0;   // (the call answers MIQ_ERANGE)
     const PatchW8Geom P = make_patch_w8_geom(conv_w8_planes(x_dtype), B, Cin, H, W, Cout, KH, KW, stride, pad);
     if (P.ok) return static_cast<size_t>(round_up(P.xp_bytes, 256));
     const StemW8Geom S = make_stem_w8_geom(B, Cin, H, W, Cout, KH, KW, stride, pad);
@@ -2081,9 +2102,16 @@ struct W8Packed {
 
 static W8Packed w8_packed_layout(int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     W8Packed p{};
+    // (sizes as make_conv_w8_geom bounds them; a rows form beyond 2 GiB is held at 2^60, which every caller refuses, and the
+    // other forms, a small multiple of Cout * Cin, are computed only below that)
+    if (!all_below_2_31({Cin, Cout}) || KH < 0 || KW < 0 || KH >= (1 << 15) || KW >= (1 << 15)) {
+        p.rows_bytes = p.total = 1ll << 60;
+        return p;
+    }
     const int64_t Cp = round_up(Cin, 8), Lp = round_up(KW * Cp, 16);
-    p.rows_bytes = round_up(Cout * KH * Lp, 256);
+    p.rows_bytes = round_up(sat_product({Cout, KH, Lp}), 256);
     p.total = p.rows_bytes;
+    if (p.rows_bytes >= (1ll << 31)) return p;
     const int planes = conv_w8_planes(x_dtype);
     if (KH == 3 && KW == 3 && Cin % 32 == 0) {
         p.patch_at = p.total;
@@ -2100,7 +2128,8 @@ static W8Packed w8_packed_layout(int x_dtype, int64_t Cin, int64_t Cout, int64_t
 
 extern "C" size_t miq_conv2d_w8_packed_weight_bytes(int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW) {
     if (Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
-    return static_cast<size_t>(w8_packed_layout(x_dtype, Cin, Cout, KH, KW).total);
+    const int64_t total = w8_packed_layout(x_dtype, Cin, Cout, KH, KW).total;
+    return total < (1ll << 31) ? static_cast<size_t>(total) : 0;   // (miq_conv2d_w8_pack_weight answers MIQ_ERANGE)
 }
 
 extern "C" int miq_conv2d_w8_pack_weight(const int8_t* w, int x_dtype, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, void* wp,
@@ -2168,9 +2197,9 @@ static int conv2d_w8_run(bool prepacked, const void* x, int x_dtype, const int8_
     if (G.M == 0 || Cout == 0) return MIQ_OK;
     MIQ_REQUIRE(x && w && out && alpha, MIQ_EINVAL, "miq_conv2d_w8: null pointer");
     const int planes = conv_w8_planes(x_dtype);
-    MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
-                MIQ_ERANGE, "miq_conv2d_w8: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
-                (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
+    MIQ_REQUIRE(conv_w8_in_range(G, planes), MIQ_ERANGE,
+                "miq_conv2d_w8: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)sat_product({planes, G.plane_bytes}), (long long)G.wp_bytes);
     const size_t xsz = x_dtype == MIQ_F32 ? 4 : 2, esz = out_dtype == MIQ_BF16 ? 2 : 4;
     MIQ_REQUIRE(miq::aligned(x, xsz) && miq::aligned(out, esz) && miq::aligned(alpha, 4) && miq::aligned(bias, 4), MIQ_EALIGN,
                 "miq_conv2d_w8: x/out/alpha/bias not aligned to their element size");
@@ -2250,6 +2279,10 @@ bool make_conv_w8_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64
     if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout < 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 ||
         pt < 0 || pb < 0 || pl < 0 || pr < 0)
         return false;
+    // (as make_conv_w8_geom: sizes below 2^31, filter / stride / dilation / padding below 2^15, long products held at 2^60)
+    if (!all_below_2_31({B, Cin, H, W, Cout})) return false;
+    for (int64_t v : {KH, KW, sh, sw, dh, dw, pt, pb, pl, pr})
+        if (v >= (1 << 15)) return false;
     const int64_t eh = dh * (KH - 1) + 1, ew = dw * (KW - 1) + 1;
     if (H + pt + pb < eh || W + pl + pr < ew) return false;
     P = std::max(std::max(pt, pb), std::max(pl, pr));
@@ -2263,10 +2296,10 @@ bool make_conv_w8_dense_geom(int64_t B, int64_t Cin, int64_t H, int64_t W, int64
     g.Cp = round_up(Cin, 8);
     g.L = kw_run * g.Cp;
     g.Lp = round_up(g.L, 16);
-    g.K = rows * g.Lp;
-    g.M = B * g.Ho * g.Wo;
-    g.plane_bytes = round_up(B * g.Hp * g.Wp * g.Cp * 2, 256);
-    g.wp_bytes = round_up(Cout * g.K, 256);
+    g.K = sat_product({rows, g.Lp});
+    g.M = sat_product({B, g.Ho, g.Wo});
+    g.plane_bytes = round_up(sat_product({B, g.Hp, g.Wp, g.Cp, 2}), 256);
+    g.wp_bytes = round_up(sat_product({Cout, g.K}), 256);
     return true;
 }
 
@@ -2283,9 +2316,7 @@ size_t conv2d_w8_dense_workspace(int x_dtype, int64_t B, int64_t Cin, int64_t H,
         return 0;
     // (0 as well for what the kernel's 32-bit offsets do not reach: the caller then takes the direct convolution)
     const int planes = conv_w8_planes(x_dtype);
-    if (planes * G.plane_bytes >= (1ll << 31) || Cout * G.K >= (1ll << 31) || G.M >= (1ll << 31) || G.K * G.Lp >= (1ll << 31) ||
-        B * (ceil_div(H * W, 64) * ceil_div(G.Cp, 64) + 8192) >= (1ll << 31))
-        return 0;
+    if (!conv_w8_in_range(G, planes) || sat_product({B, ceil_div(H * W, 64) * ceil_div(G.Cp, 64) + 8192}) >= (1ll << 31)) return 0;
     return static_cast<size_t>(planes * G.plane_bytes + G.wp_bytes);
 }
 
@@ -2300,9 +2331,9 @@ int conv2d_w8_dense(const void* x, int x_dtype, const int8_t* w, int64_t B, int6
                 "miq_conv2d_general: bad geometry");
     if (G.M == 0 || Cout == 0) return MIQ_OK;
     const int planes = conv_w8_planes(x_dtype);
-    MIQ_REQUIRE(planes * G.plane_bytes < (1ll << 31) && Cout * G.K < (1ll << 31) && G.M < (1ll << 31) && G.K * G.Lp < (1ll << 31),
-                MIQ_ERANGE, "miq_conv2d_general: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
-                (long long)(planes * G.plane_bytes), (long long)(Cout * G.K));
+    MIQ_REQUIRE(conv_w8_in_range(G, planes), MIQ_ERANGE,
+                "miq_conv2d_general: padded activation planes (%lld B) and packed weights (%lld B) must stay below 2 GiB",
+                (long long)sat_product({planes, G.plane_bytes}), (long long)G.wp_bytes);
     const size_t need = conv2d_w8_dense_workspace(x_dtype, B, Cin, H, W, Cout, KH, KW, sh, sw, pt, pb, pl, pr, dh, dw);
     MIQ_REQUIRE(workspace && workspace_bytes >= need, MIQ_EWORKSPACE, "miq_conv2d_general: needs %zu bytes of workspace (got %zu)",
                 need, workspace_bytes);
