@@ -13,6 +13,9 @@
  *    returns a thread-local, human-readable message.  Arguments are validated before
  *    anything is launched, so a failed call has no effect on device memory.
  *  - Tensors are dense and contiguous in the stated layout.
+ *  - Sizes may be any int64: an entry point bounds them before it does arithmetic on them (a dimension at or beyond
+ *    2^31, a filter size / stride / dilation / padding at or beyond 2^15, or a byte count beyond what a kernel indexes
+ *    gives MIQ_ERANGE or MIQ_EINVAL), and a *_workspace / *_bytes query answers 0 for what the call would refuse.
  */
 #ifndef MIQ_H
 #define MIQ_H
