@@ -449,8 +449,9 @@ extern "C" int miq_quantize_tensor_i8(const void* x, int x_dtype, int64_t planes
                 "miq_quantize_tensor_i8: negative size");
     MIQ_REQUIRE(x_dtype == MIQ_F32 || x_dtype == MIQ_F16 || x_dtype == MIQ_BF16, MIQ_EINVAL,
                 "miq_quantize_tensor_i8: x_dtype must be MIQ_F32, MIQ_F16 or MIQ_BF16 (got %d)", x_dtype);
-    MIQ_REQUIRE(all_below_2_31({planes, H, W, pad_top, pad_bottom, pad_left, pad_right}), MIQ_ERANGE,
-                "miq_quantize_tensor_i8: planes, H, W and the paddings must each stay below 2^31");
+    // (an unframed tensor may be one row of more than 2^31 elements: the sums below only need room for the paddings)
+    MIQ_REQUIRE(planes < (1ll << 62) && H < (1ll << 62) && W < (1ll << 62) && all_below_2_31({pad_top, pad_bottom, pad_left, pad_right}),
+                MIQ_ERANGE, "miq_quantize_tensor_i8: sizes must stay below 2^62 and the paddings below 2^31");
     const int64_t Hf = H + pad_top + pad_bottom, Wf = W + pad_left + pad_right;
     const int64_t n_out = size_product({planes, Hf, Wf}), n_in = size_product({planes, H, W});
     MIQ_REQUIRE(n_out >= 0, MIQ_ERANGE, "miq_quantize_tensor_i8: the output's element count does not fit 62 bits");
