@@ -470,9 +470,58 @@ def fuzz_activation(n):
             report("activation", "layer", args)
 
 
+def fuzz_small_kernels(n):
+    """The method-by-method pieces behind Qop (row maximum, quantize with given parameters, dequantize by row / by channel,
+    the float epilogue) and the byte transpose, against torch's own fp32 operators (one rounding per step) bit for bit."""
+    g = torch.Generator(device=dev).manual_seed(seed + 8)
+    for it in range(n):
+        kind = int(rng.integers(0, 6))
+        rows = int(pick([1, 2, 3, 17, 64, 100, 255, 1000]))
+        cols = int(pick([1, 2, 5, 16, 63, 64, 129, 1000, 4096, 5001]))
+        dt = pick([torch.float32, torch.float16, torch.bfloat16])
+        args = (kind, rows, cols, dt)
+        if kind == 0:
+            w = (torch.randn(rows, cols, device=dev, generator=g) * 3).to(dt)
+            ok = torch.equal(N.row_max(w), w.float().max(dim=1).values)
+        elif kind == 1:   # Qop.py:157: round(w / scale + zp), clamp; per row and per tensor
+            w = (torch.randn(rows, cols, device=dev, generator=g) * 3).to(torch.float32)
+            per_row = bool(rng.integers(0, 2))
+            sc = torch.rand(rows if per_row else 1, device=dev, generator=g) * 0.05 + 1e-3
+            zp = torch.randint(-20, 20, (rows if per_row else 1,), device=dev, generator=g).float() if rng.integers(0, 2) else None
+            q = N.quantize_rows_given_i8(w, sc, zp)
+            v = w / sc.view(-1, 1)
+            if zp is not None:
+                v = v + zp.view(-1, 1)
+            ok = torch.equal(q, torch.clamp(torch.round(v), -128, 127).to(torch.int8))
+        elif kind == 2:
+            q = ri8((rows, cols), g)
+            sc = torch.rand(rows, device=dev, generator=g) * 0.05 + 1e-3
+            zp = torch.randint(-20, 20, (rows,), device=dev, generator=g) if rng.integers(0, 2) else None
+            ref = sc.view(-1, 1) * (q.float() - (zp.float().view(-1, 1) if zp is not None else 0.0))
+            ok = torch.equal(N.dequantize_rows_i8(q, sc, zp), ref)
+        elif kind in (3, 4):
+            C, inner = int(pick([1, 3, 64, 130])), int(pick([1, 7, 49, 196, 1024]))
+            y = torch.randn(min(rows, 9), C, inner, device=dev, generator=g) * 100
+            a = torch.rand(C, device=dev, generator=g) * 0.05 + 1e-3
+            b = torch.randn(C, device=dev, generator=g) * 5 if rng.integers(0, 2) else None
+            if kind == 3:   # Qop.dequantize with activation=True: scale[c] * (y - zp[c])
+                ref = a.view(1, -1, 1) * (y - (b.view(1, -1, 1) if b is not None else 0.0))
+                ok = torch.equal(N.dequantize_channels_f32(y, a, b), ref)
+            else:
+                ref = (y + (b.view(1, -1, 1) if b is not None else 0.0)) * a.view(1, -1, 1) + 0.75
+                ok = torch.equal(N.epilogue_channels_f32(y, b, a, 0.75), ref)
+            args = (kind, tuple(y.shape), b is not None)
+        else:
+            src = ri8((rows, cols), g)
+            ok = torch.equal(N.transpose_i8(src), src.t().contiguous())
+        if not ok:
+            report("small_kernels", "mismatch", args)
+
+
 FAMILIES = {"gemm": fuzz_gemm, "conv": fuzz_conv, "gemm_w8": fuzz_gemm_w8, "conv_w8": fuzz_conv_w8,
             "conv_general": fuzz_conv_general, "quantizer": fuzz_quantizer, "layers": fuzz_layers,
-            "layers_wa": fuzz_layers_wa, "pool": fuzz_pool, "activation": fuzz_activation}
+            "layers_wa": fuzz_layers_wa, "pool": fuzz_pool, "activation": fuzz_activation,
+            "small_kernels": fuzz_small_kernels}
 
 
 def run(families, cases, s):
