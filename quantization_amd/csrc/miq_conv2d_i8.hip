@@ -497,7 +497,10 @@ __device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* ti
 
 // CL = channels-last output: the weight fragment is then the MFMA's first operand, so that a lane ends with four
 // consecutive channels of one pixel (store_pixel_channels) instead of four consecutive pixels of one channel.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool STREAM, bool CL = false>
+// STAGES = 2: double buffer, one __syncthreads per K-tile (which drains the DMA: the fetch of K-tile t + 1 overlaps only
+// the MFMAs of K-tile t).  STAGES > 2: the GEMM's ring (gemm_i8_kernel): STAGES - 1 K-tiles in flight behind a counted
+// vmcnt, one raw barrier per K-tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool STREAM, bool CL = false, int STAGES = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -558,17 +561,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
     const int nt = (g.Kp + kTileK - 1) / kTileK;
     const int lo0 = frag_lane_offset(lane, 0), lo1 = frag_lane_offset(lane, 1);
 
-    stage_pixels(smem, 0);
-    stage_rows<BN, NWAVES>(rw, smem + BM * kTileK, n0, g.Cout, g.Kp, 0, wave, lane);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        char* cur = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * STAGE;
-            stage_pixels(nxt, t + 1);
-            stage_rows<BN, NWAVES>(rw, nxt + BM * kTileK, n0, g.Cout, g.Kp, t + 1, wave, lane);
-        }
+    auto stage = [&](char* buf, int kt) {   // (a K-tile past the end is requested past K: zero-filled, no traffic)
+        stage_pixels(buf, kt);
+        stage_rows<BN, NWAVES>(rw, buf + BM * kTileK, n0, g.Cout, g.Kp, kt, wave, lane);
+    };
+    auto mma_tile = [&](const char* cur) {
         const char* at = cur + wm * WM * kTileK;
         const char* wt = cur + BM * kTileK + wn * WN * kTileK;
 #pragma unroll
@@ -586,7 +583,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_i8_kernel(ConvArg
                     acc[i][j] = CL ? __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], af[i], acc[i][j], 0, 0, 0)
                                    : __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
+    };
+    if constexpr (STAGES == 2) {
+        stage(smem, 0);
         __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) stage(smem + ((t + 1) & 1) * STAGE, t + 1);
+            mma_tile(smem + (t & 1) * STAGE);
+            __syncthreads();
+        }
+    } else {
+        // every wave issues the same number of DMA instructions per K-tile, so one count serves all
+        static_assert((BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "pieces must divide among the waves");
+        constexpr int kLoads = (BM / 8 + BN / 8) / NWAVES;
+        constexpr int kKeep = kLoads * (STAGES - 2);
+        static_assert(kKeep <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int s0 = 0; s0 < STAGES - 1; ++s0) stage(smem + s0 * STAGE, s0);
+        int slot_t = 0, fill = STAGES - 1;   // buffer of K-tile t; buffer K-tile t + STAGES - 1 goes into
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKeep) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage(smem + fill * STAGE, t + STAGES - 1);
+            mma_tile(smem + slot_t * STAGE);
+            slot_t = slot_t + 1 == STAGES ? 0 : slot_t + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills requested for K-tiles past the end
+        __syncthreads();                                    // every wave has read the last K-tile: an epilogue may reuse the LDS
     }
 
     if constexpr (CL) {   // D[r][c]: r = 4*(lane>>4) + reg -> channel, c = lane&15 -> pixel
@@ -1873,14 +1898,14 @@ int launch_stem(StemArgs g, int64_t B, hipStream_t st) {
     return check_launch("conv_stem_kernel");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool CL = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT, bool CL = false, int STAGES = 2>
 int launch_tile(ConvArgs g, hipStream_t st) {
     g.tiles_m = static_cast<int>(ceil_div(g.M, BM));
     g.tiles_n = static_cast<int>(ceil_div(g.Cout, BN));
-    const int lds = 2 * (BM + BN) * kTileK;
-    void (*kern)(ConvArgs) = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false, CL>;
+    const int lds = STAGES * (BM + BN) * kTileK;
+    void (*kern)(ConvArgs) = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, false, CL, STAGES>;
     if constexpr (!CL) {
-        if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true>;
+        if (g.stream_out) kern = conv_i8_kernel<BM, BN, WAVES_M, WAVES_N, OUT, true, false, STAGES>;
     }
     if (int rc = allow_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     kern<<<g.tiles_m * g.tiles_n, 64 * WAVES_M * WAVES_N, lds, st>>>(g);
@@ -1913,6 +1938,15 @@ int launch(const ConvArgs& g, hipStream_t st) {
             case 'd': return launch_tile<128, 128, 2, 2, OUT>(g, st);
             case 'e': return launch_tile<128, 64, 2, 2, OUT>(g, st);
             case 'p': return launch_pipe<OUT>(g, st);
+#ifndef MIQ_NO_DEV_SWITCHES
+            case 'E': return launch_tile<128, 64, 2, 2, OUT, false, 3>(g, st);    // rings
+            case 'F': return launch_tile<128, 64, 2, 2, OUT, false, 4>(g, st);
+            case 'D': return launch_tile<128, 128, 2, 2, OUT, false, 3>(g, st);
+            case 'G': return launch_tile<128, 128, 2, 4, OUT, false, 3>(g, st);
+            case 'H': return launch_tile<64, 64, 2, 2, OUT, false, 4>(g, st);
+            case 'I': return launch_tile<128, 128, 2, 4, OUT, false, 4>(g, st);
+            case 'J': return launch_tile<128, 64, 4, 2, OUT, false, 4>(g, st);
+#endif
             default: break;
         }
     }
