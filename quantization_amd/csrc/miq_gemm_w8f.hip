@@ -1653,29 +1653,48 @@ __global__ __launch_bounds__(256) void stem_w8_prep_kernel(const T* __restrict__
                                                            const int8_t* __restrict__ w, uint4* __restrict__ wp, uint32_t wchunks,
                                                            int Cout, int KH, int KW) {
     if (static_cast<int>(blockIdx.x) < n_prep) {
-        for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < npix; idx += 256u * n_prep) {
-            const uint32_t rowi = idx / Wp, s = idx - rowi * Wp, b = rowi / Hp, hp = rowi - b * Hp;
-            const int h = static_cast<int>(hp) - pad, ww = static_cast<int>(s) - pad;
-            float fh[4] = {0.f, 0.f, 0.f, 0.f}, fl[4] = {0.f, 0.f, 0.f, 0.f};
-            if (h >= 0 && h < H && ww >= 0 && ww < W) {
-                const T* src = x + (static_cast<size_t>(b) * Cin * H + h) * W + ww;
-                const size_t cs = static_cast<size_t>(H) * W;
+        // Four pixels a thread (256 apart, so that a wave's loads and stores stay contiguous), every load issued before the
+        // first conversion: one pixel a thread left too few bytes in flight to fill the memory pipes.
+        const size_t cs = static_cast<size_t>(H) * W;
+        for (uint32_t base = blockIdx.x * 1024u + threadIdx.x; base < npix; base += 1024u * n_prep) {
+            // (loads without branches: a padding pixel reads the nearest pixel of its image and drops it)
+            T raw[4][4];
+            bool real[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t idx = base + 256u * k, idc = min(idx, npix - 1u);
+                const uint32_t rowi = idc / Wp, s = idc - rowi * Wp, b = rowi / Hp, hp = rowi - b * Hp;
+                const int h = static_cast<int>(hp) - pad, ww = static_cast<int>(s) - pad;
+                real[k] = idx < npix && h >= 0 && h < H && ww >= 0 && ww < W;
+                const size_t first = (static_cast<size_t>(b) * Cin * H + min(max(h, 0), H - 1)) * W + min(max(ww, 0), W - 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) raw[k][c] = x[first + min(c, Cin - 1) * cs];   // (channels past Cin: dropped below)
+            }
+            float v[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = (real[k] && c < Cin) ? to_f32(raw[k][c]) : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t idx = base + 256u * k;
+                if (idx >= npix) break;
+                float fh[4], fl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (c >= Cin) break;
-                    const float v = to_f32(src[c * cs]);
-                    fh[c] = kPlaneF16<T, NP> ? v : bf16_round(v);   // fp16 activations as one plane keep their format
+                    const float e = v[k][c];
+                    fh[c] = kPlaneF16<T, NP> ? e : bf16_round(e);   // fp16 activations as one plane keep their format
                     if constexpr (NP == 2) {
-                        if (__builtin_isinf(fh[c]) && !__builtin_isinf(v))   // rounded past the largest bf16: truncate instead
-                            fh[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
-                        fl[c] = (__builtin_isinf(fh[c]) || fh[c] != fh[c]) ? 0.0f : __fsub_rn(v, fh[c]);
+                        if (__builtin_isinf(fh[c]) && !__builtin_isinf(e))   // rounded past the largest bf16: truncate instead
+                            fh[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, e) & 0xffff0000u);
+                        fl[c] = (__builtin_isinf(fh[c]) || fh[c] != fh[c]) ? 0.0f : __fsub_rn(e, fh[c]);
                     }
                 }
+                if constexpr (kPlaneF16<T, NP>)   // (fh holds the fp16 values themselves: see below)
+                    xp[idx] = uint4{pack2_f16(fh[0], fh[1]), pack2_f16(fh[2], fh[3]), 0u, 0u};
+                else
+                    xp[idx] = uint4{pack2_bf16(fh[0], fh[1]), pack2_bf16(fh[2], fh[3]), pack2_bf16(fl[0], fl[1]), pack2_bf16(fl[2], fl[3])};
             }
-            if constexpr (kPlaneF16<T, NP>)   // (fh holds the fp16 values themselves: see below)
-                xp[idx] = uint4{pack2_f16(fh[0], fh[1]), pack2_f16(fh[2], fh[3]), 0u, 0u};
-            else
-                xp[idx] = uint4{pack2_bf16(fh[0], fh[1]), pack2_bf16(fh[2], fh[3]), pack2_bf16(fl[0], fl[1]), pack2_bf16(fl[2], fl[3])};
         }
         return;
     }
@@ -1886,7 +1905,7 @@ int run_stem_w8(const StemW8Geom& P, const void* x, int x_dtype, const int8_t* w
     uint4* wp = wp_packed ? static_cast<uint4*>(const_cast<void*>(wp_packed))
                           : reinterpret_cast<uint4*>(static_cast<char*>(workspace) + round_up(P.xp_bytes, 256));
     const uint32_t npix = static_cast<uint32_t>(P.xp_bytes / kChunk), wchunks = static_cast<uint32_t>(P.wp_bytes / kChunk);
-    const int n_prep = static_cast<int>(std::min<int64_t>(ceil_div(npix, 256), 1 << 20));
+    const int n_prep = static_cast<int>(std::min<int64_t>(ceil_div(npix, 1024), 1 << 20));   // four pixels a thread
     const int n_pack = wp_packed ? 0 : static_cast<int>(std::min<int64_t>(ceil_div(wchunks, 256), 4096));
 #define MIQ_STEM_PREP(T, NP)                                                                                               \
     stem_w8_prep_kernel<T, NP><<<n_prep + n_pack, 256, 0, st>>>(static_cast<const T*>(x), xp, (int)Cin, (int)H, (int)W, (int)P.Hp, \
